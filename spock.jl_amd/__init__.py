@@ -7,6 +7,9 @@ from .problem import (CONE_NONNEG, CONE_NONPOS, CONE_REALS, CONE_SOC, CONE_ZEROS
                       FlatProblem, RiskMeasure, ScenarioTree, UniformRectangle, flatten_problem,
                       generate_scenario_tree_uniform_branching_factor_v2, get_uniform_rms_avar_v2,
                       get_uniform_rms_tv_v2, get_uniform_rms_v2)
+from .model import (CP, LOG, SILENT, SP, AlgorithmOptions, Model, QNewtonOptions, SolverOptions, VERBOSE_LEVEL,
+                    build_model, solve_model, solve_model_bang)
+from ._lib import SpockError, load_library
 from .examples import L_norm_sq, get_car_fixture, get_random_linear_specs, get_server_heat_specs
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,445 @@
+// spock_abi.cpp -- the C ABI of include/spock_amd.h: handle management and the device-resident
+// Chambolle-Pock driver (run_cp!, /root/reference/src/model_algorithms/cp.jl:188-232).
+//
+// Driver design: the iteration loop never returns to the host for a decision.  Each instance has a
+// control block in device memory (Ctl); the first kernel of iteration k+1 runs the termination test of
+// iteration k (should_terminate!, cp.jl:54-123) and, once an instance is done, every later kernel for
+// it exits immediately, so the state freezes at exactly the iterate the reference would stop at.  The
+// host replays a captured hipGraph of `graph_iters` iterations and polls the control blocks in between.
+// z/v ping-pong between two buffers ("z <- zbar" at lambda = 1 is a pointer swap, cp.jl:34-52).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spock_amd.h"
+#include "spock_internal.hpp"
+#include "spock_rt.hpp"
+
+using namespace spock;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+struct spock_handle_s {
+    HostProblem hp;
+    BuildProducts bp;
+    int alg = SPOCK_ALG_CP, device = 0, batch = 1, max_iter = 5000, graph_iters = 32;
+    double L_norm = 10.;
+    void *stream = nullptr, *ev0 = nullptr, *ev1 = nullptr, *graph = nullptr;
+    // device memory
+    double *d_mats = nullptr, *d_z[2] = {nullptr, nullptr}, *d_v[2] = {nullptr, nullptr};
+    double *d_dbuf = nullptr, *d_qroot = nullptr, *d_partials = nullptr, *d_x0 = nullptr, *d_hist = nullptr;
+    Ctl *d_ctl = nullptr;
+    int hist_cap = 0;
+    // single-instance buffers of the operator-level entry points
+    double *o_z[2] = {nullptr, nullptr}, *o_v[2] = {nullptr, nullptr}, *o_dbuf = nullptr, *o_qroot = nullptr,
+           *o_partials = nullptr, *o_x0 = nullptr;
+    Ctl *o_ctl = nullptr;
+    std::vector<Ctl> h_ctl;
+    double last_ms = 0.;
+    int last_iters = 0;
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+#define RTCHECK(expr)                                                                          \
+    do {                                                                                       \
+        int _e = (expr);                                                                       \
+        if (_e != 0) return fail(SPOCK_ERR_HIP, std::string(#expr) + ": " + rt::err(_e));      \
+    } while (0)
+
+template <class T>
+int dev_alloc(spock_handle_s *h, T **p, size_t count) {
+    void *q = nullptr;
+    int e = rt::dmalloc(&q, count * sizeof(T));
+    if (e != 0) return e;
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return rt::dzero(q, count * sizeof(T), h->stream);
+}
+
+KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
+    KArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.dm = h->bp.dm;
+    a.mats = h->d_mats;
+    if (!op) {
+        a.z_in = h->d_z[parity]; a.v_in = h->d_v[parity];
+        a.z_out = h->d_z[1 - parity]; a.v_out = h->d_v[1 - parity];
+        a.dbuf = h->d_dbuf; a.qroot = h->d_qroot; a.partials = h->d_partials; a.ctl = h->d_ctl; a.x0 = h->d_x0;
+        a.hist = h->d_hist; a.hist_cap = h->hist_cap; a.batch = h->batch;
+    } else {
+        a.z_in = h->o_z[0]; a.v_in = h->o_v[0]; a.z_out = h->o_z[1]; a.v_out = h->o_v[1];
+        a.dbuf = h->o_dbuf; a.qroot = h->o_qroot; a.partials = h->o_partials; a.ctl = h->o_ctl; a.x0 = h->o_x0;
+        a.hist = nullptr; a.hist_cap = 0; a.batch = 1;
+    }
+    a.parity = parity;
+    a.flags = flags;
+    return a;
+}
+
+// the kernels of one evaluation of the CP operator (+ residuals) on input buffer `parity`
+int launch_iteration(spock_handle_s *h, bool op, int parity, unsigned flags, bool phase_a = true, bool phase_b = true) {
+    const KArgs a = make_args(h, op, parity, flags);
+    if (h->bp.dm.t0 == 0) return launch_group(MODE_FULL, a, h->stream);
+    int e = 0;
+    if (phase_a) e = launch_group(MODE_SUB_A, a, h->stream);
+    if (e == 0) e = launch_group(MODE_CROWN, a, h->stream);
+    if (e == 0 && phase_b) e = launch_group(MODE_SUB_B, a, h->stream);
+    return e;
+}
+
+int ensure_op_buffers(spock_handle_s *h) {
+    if (h->o_ctl) return 0;
+    const Dims &dm = h->bp.dm;
+    int e = 0;
+    for (int k = 0; k < 2 && !e; ++k) { e = dev_alloc(h, &h->o_z[k], (size_t)dm.nz); if (!e) e = dev_alloc(h, &h->o_v[k], (size_t)dm.nv); }
+    if (!e) e = dev_alloc(h, &h->o_dbuf, (size_t)dm.nn * dm.nu);
+    if (!e) e = dev_alloc(h, &h->o_qroot, (size_t)dm.nsub * dm.nx);
+    if (!e) e = dev_alloc(h, &h->o_partials, (size_t)(dm.nsub + 1) * kPartialStride);
+    if (!e) e = dev_alloc(h, &h->o_x0, (size_t)dm.nx);
+    if (!e) e = dev_alloc(h, &h->o_ctl, 1);
+    return e;
+}
+
+Ctl fresh_ctl(const spock_handle_s *h, double gamma, double sigma, double tol, int verbose) {
+    Ctl c;
+    std::memset(&c, 0, sizeof(c));
+    c.max_iter = h->max_iter;
+    c.log_mode = verbose;
+    c.alg = h->alg;
+    c.res0[0] = -INFINITY; c.res0[1] = -INFINITY;   // cpock.jl:186
+    c.xi1 = c.xi2 = c.xi = NAN;
+    c.gamma = gamma; c.sigma = sigma; c.tol = tol;
+    return c;
+}
+
+// run one operator-style launch sequence: inputs (may be null = zeros) -> op buffers -> outputs
+int run_op(spock_handle_s *h, const double *z_in, const double *v_in, const double *zbar_in, const double *x0,
+           double gamma, double sigma, unsigned flags, bool phase_a, bool phase_b, double *z_out, double *v_out) {
+    const Dims &dm = h->bp.dm;
+    RTCHECK(ensure_op_buffers(h));
+    const size_t bz = sizeof(double) * dm.nz, bv = sizeof(double) * dm.nv;
+    if (z_in) RTCHECK(rt::h2d(h->o_z[0], z_in, bz, h->stream)); else RTCHECK(rt::dzero(h->o_z[0], bz, h->stream));
+    if (v_in) RTCHECK(rt::h2d(h->o_v[0], v_in, bv, h->stream)); else RTCHECK(rt::dzero(h->o_v[0], bv, h->stream));
+    if (zbar_in) RTCHECK(rt::h2d(h->o_z[1], zbar_in, bz, h->stream)); else RTCHECK(rt::dzero(h->o_z[1], bz, h->stream));
+    RTCHECK(rt::dzero(h->o_v[1], bv, h->stream));
+    if (x0) RTCHECK(rt::h2d(h->o_x0, x0, sizeof(double) * dm.nx, h->stream)); else RTCHECK(rt::dzero(h->o_x0, sizeof(double) * dm.nx, h->stream));
+    Ctl c = fresh_ctl(h, gamma, sigma, 0., SPOCK_SILENT);
+    RTCHECK(rt::h2d(h->o_ctl, &c, sizeof(Ctl), h->stream));
+    RTCHECK(launch_iteration(h, true, 0, flags | F_NO_CTL, phase_a, phase_b));
+    if (z_out) RTCHECK(rt::d2h(z_out, h->o_z[1], bz, h->stream));
+    if (v_out) RTCHECK(rt::d2h(v_out, h->o_v[1], bv, h->stream));
+    RTCHECK(rt::sync(h->stream));
+    return SPOCK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *spock_last_error(void) { return g_err.c_str(); }
+int spock_version(void) { return SPOCK_AMD_VERSION; }
+
+int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handle_t *out) {
+    if (!p || !out) return fail(SPOCK_ERR_BAD_ARG, "problem and out must not be NULL");
+    *out = nullptr;
+    if (!p->A || !p->B || !p->Q || !p->R || !p->QN || !p->E || !p->F || !p->b || (p->n_cones > 0 && (!p->cone_kind || !p->cone_dim)))
+        return fail(SPOCK_ERR_BAD_ARG, "NULL array in spock_problem_t");
+    if (p->d <= 1) return fail(SPOCK_ERR_BAD_ARG, "Branching factor d must be larger than 1");
+    if (p->N < 2 || p->N > kMaxStages || p->nx < 1 || p->nu < 1 || p->ny < 1) return fail(SPOCK_ERR_BAD_ARG, "invalid N / nx / nu / ny");
+    const int alg = o && o->algorithm ? o->algorithm : SPOCK_ALG_CP;
+    if (alg != SPOCK_ALG_CP && alg != SPOCK_ALG_SP) return fail(SPOCK_ERR_UNSUPPORTED, "This combination of solver options is not supported.");  // model.jl:295
+    if (alg == SPOCK_ALG_SP) return fail(SPOCK_ERR_UNSUPPORTED, "SP (SuperMann) driver is not on the GPU path yet; use SPOCK_ALG_CP");
+
+    spock_handle_s *h = new spock_handle_s();
+    HostProblem &hp = h->hp;
+    hp.N = p->N; hp.d = p->d; hp.nx = p->nx; hp.nu = p->nu; hp.ny = p->ny;
+    const int N = hp.N, d = hp.d, nx = hp.nx, nu = hp.nu, ny = hp.ny;
+    long n = 0; { long c = 1; for (int t = 0; t < N; ++t) { n += c; c *= d; } }
+    long nl = 1; for (int t = 0; t < N - 1; ++t) nl *= d;
+    // the solver assumes the uniform breadth-first layout (children contiguous, implicit_l.jl:712-714)
+    if (p->anc || p->w) {
+        for (long j = 0; j < n; ++j) {
+            const int ea = j == 0 ? -1 : (int)((j - 1) / d), ew = j == 0 ? -1 : (int)((j + 1) % d);
+            if ((p->anc && p->anc[j] != ea) || (p->w && p->w[j] != ew)) {
+                delete h;
+                return fail(SPOCK_ERR_UNSUPPORTED, "scenario tree is not the uniform breadth-first tree of generate_scenario_tree_uniform_branching_factor_v2");
+            }
+        }
+    }
+    hp.nQ = p->nQ; hp.nR = p->nR; hp.nQN = p->nQN;
+    if (!(hp.nQ == 1 || hp.nQ == n - 1) || !(hp.nR == 1 || hp.nR == n - 1) || !(hp.nQN == 1 || hp.nQN == nl)) {
+        delete h;
+        return fail(SPOCK_ERR_BAD_ARG, "nQ, nR, nQN must be 1 or n-1 / n-1 / n_leaf");
+    }
+    hp.A.assign(p->A, p->A + (size_t)d * nx * nx);
+    hp.B.assign(p->B, p->B + (size_t)d * nx * nu);
+    hp.Q.assign(p->Q, p->Q + (size_t)hp.nQ * nx * nx);
+    hp.R.assign(p->R, p->R + (size_t)hp.nR * nu * nu);
+    hp.QN.assign(p->QN, p->QN + (size_t)hp.nQN * nx * nx);
+    hp.E.assign(p->E, p->E + (size_t)ny * d);
+    hp.F.assign(p->F, p->F + (size_t)ny * d);
+    hp.b.assign(p->b, p->b + ny);
+    hp.cone_kind.assign(p->cone_kind, p->cone_kind + p->n_cones);
+    hp.cone_dim.assign(p->cone_dim, p->cone_dim + p->n_cones);
+    hp.x_min = p->x_min; hp.x_max = p->x_max; hp.u_min = p->u_min; hp.u_max = p->u_max;
+
+    h->alg = alg;
+    h->device = o ? o->device : 0;
+    h->batch = o && o->batch > 0 ? o->batch : 1;
+    h->L_norm = (o && std::isfinite(o->L_norm) && o->L_norm > 0.) ? o->L_norm : (alg == SPOCK_ALG_CP ? 10. : 3.28);  // cpock.jl:63, models/spock.jl:64
+    h->max_iter = o && o->max_iter > 0 ? o->max_iter : (alg == SPOCK_ALG_CP ? 5000 : 1000);                          // cp.jl:190, sp.jl:360
+    int gi = o ? o->graph_iters : 0;
+    if (const char *e = std::getenv("SPOCK_AMD_GRAPH_ITERS")) gi = std::atoi(e);
+    if (gi == 0) gi = 32;
+    if (gi > 0 && (gi & 1)) gi += 1;   // an even count brings the ping-pong parity back to 0
+    h->graph_iters = gi;
+    int split = o ? o->split_stage : 0;
+    if (const char *e = std::getenv("SPOCK_AMD_SPLIT_STAGE")) split = std::atoi(e);
+
+    bool unsupported = false;
+    const std::string msg = host_build(hp, split, h->bp, unsupported);
+    if (!msg.empty()) { delete h; return fail(unsupported ? SPOCK_ERR_UNSUPPORTED : SPOCK_ERR_BUILD, msg); }
+    const Dims &dm = h->bp.dm;
+
+    auto bail = [&](int e, const char *what) {
+        std::string m = std::string(what) + ": " + rt::err(e);
+        spock_destroy(h);
+        return fail(SPOCK_ERR_HIP, m);
+    };
+    int e = rt::set_device(h->device);
+    if (e) return bail(e, "hipSetDevice");
+    if ((e = rt::stream_create(&h->stream))) return bail(e, "hipStreamCreate");
+    if ((e = rt::event_create(&h->ev0)) || (e = rt::event_create(&h->ev1))) return bail(e, "hipEventCreate");
+    const size_t B = (size_t)h->batch;
+    if ((e = dev_alloc(h, &h->d_mats, h->bp.mats.size()))) return bail(e, "hipMalloc(matrix pool)");
+    if ((e = rt::h2d(h->d_mats, h->bp.mats.data(), h->bp.mats.size() * sizeof(double), h->stream))) return bail(e, "upload");
+    for (int k = 0; k < 2; ++k) {
+        if ((e = dev_alloc(h, &h->d_z[k], B * dm.nz)) || (e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
+    }
+    h->hist_cap = h->max_iter + 2;
+    if ((e = dev_alloc(h, &h->d_dbuf, B * dm.nn * dm.nu)) || (e = dev_alloc(h, &h->d_qroot, B * dm.nsub * dm.nx)) ||
+        (e = dev_alloc(h, &h->d_partials, B * (dm.nsub + 1) * kPartialStride)) || (e = dev_alloc(h, &h->d_x0, B * dm.nx)) ||
+        (e = dev_alloc(h, &h->d_hist, B * (size_t)h->hist_cap * kHistStride)) || (e = dev_alloc(h, &h->d_ctl, B)))
+        return bail(e, "hipMalloc(workspace)");
+    h->h_ctl.assign(B, fresh_ctl(h, 0., 0., 0., SPOCK_SILENT));
+    for (auto &c : h->h_ctl) c.done = 1;
+    if ((e = rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream))) return bail(e, "upload");
+    if ((e = rt::sync(h->stream))) return bail(e, "hipStreamSynchronize");
+    *out = h;
+    return SPOCK_OK;
+}
+
+int spock_destroy(spock_handle_t h) {
+    if (!h) return SPOCK_OK;
+    if (h->stream) rt::sync(h->stream);
+    if (h->graph) rt::graph_destroy(h->graph);
+    for (void *p : h->allocs) rt::dfree(p);
+    if (h->ev0) rt::event_destroy(h->ev0);
+    if (h->ev1) rt::event_destroy(h->ev1);
+    if (h->stream) rt::stream_destroy(h->stream);
+    delete h;
+    return SPOCK_OK;
+}
+
+int spock_sizes(spock_handle_t h, spock_sizes_t *s) {
+    if (!h || !s) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    const Dims &dm = h->bp.dm;
+    s->n = dm.n; s->n_nonleaf = dm.nn; s->n_leaf = dm.nl; s->nz = dm.nz; s->nv = dm.nv; s->batch = h->batch;
+    s->z_x = dm.zx; s->z_u = dm.zu; s->z_s = dm.zs; s->z_tau = dm.zt; s->z_y = dm.zy;
+    s->v1 = 0; s->v2 = dm.o2; s->v3 = dm.o3; s->v4 = dm.o4; s->v5 = dm.o5; s->v6 = dm.o6; s->v7 = dm.o7;
+    s->v11 = dm.o11; s->v12 = dm.o12; s->v13 = dm.o13; s->v14 = dm.o14;
+    s->split_stage = dm.t0; s->n_subtrees = dm.nsub; s->graph_iters = h->graph_iters;
+    return SPOCK_OK;
+}
+
+int spock_solve(spock_handle_t h, const double *x0, double tol, int32_t verbose, const double *z0, const double *v0,
+                double gamma, double sigma, spock_result_t *results) {
+    if (!h || !x0) return fail(SPOCK_ERR_BAD_ARG, "handle and x0 must not be NULL");
+    if ((z0 == nullptr) != (v0 == nullptr)) return fail(SPOCK_ERR_BAD_ARG, "z0 and v0 must be given together");  // cpock.jl:180-183
+    if (verbose != SPOCK_SILENT && verbose != SPOCK_LOG) return fail(SPOCK_ERR_BAD_ARG, "verbose must be SPOCK_SILENT or SPOCK_LOG");
+    if (!(tol >= 0.)) return fail(SPOCK_ERR_BAD_ARG, "tol must be non-negative");
+    const Dims &dm = h->bp.dm;
+    const size_t B = (size_t)h->batch;
+    if (!(std::isfinite(gamma) && std::isfinite(sigma))) { sigma = 0.99 / std::sqrt(h->L_norm); gamma = sigma; }  // cp.jl:198-201
+    if (!(gamma > 0. && sigma > 0.)) return fail(SPOCK_ERR_BAD_ARG, "gamma and sigma must be positive");
+
+    RTCHECK(rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream));
+    if (z0) {
+        RTCHECK(rt::h2d(h->d_z[0], z0, B * dm.nz * sizeof(double), h->stream));
+        RTCHECK(rt::h2d(h->d_v[0], v0, B * dm.nv * sizeof(double), h->stream));
+    }
+    h->h_ctl.assign(B, fresh_ctl(h, gamma, sigma, tol, verbose));
+    RTCHECK(rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream));
+
+    const int G = h->graph_iters > 0 ? h->graph_iters : -h->graph_iters;   // negative: eager launches
+    const bool use_graph = h->graph_iters > 0 && rt::graphs_supported();
+    if (use_graph && !h->graph) {
+        RTCHECK(rt::capture_begin(h->stream));
+        int e = 0;
+        for (int it = 0; it < G && e == 0; ++it) e = launch_iteration(h, false, it & 1, 0);
+        void *exec = nullptr;
+        const int e2 = rt::capture_end(h->stream, &exec);
+        if (e) return fail(SPOCK_ERR_HIP, std::string("kernel launch during capture: ") + rt::err(e));
+        if (e2) return fail(SPOCK_ERR_HIP, std::string("hipStreamEndCapture/hipGraphInstantiate: ") + rt::err(e2));
+        h->graph = exec;
+    }
+    RTCHECK(rt::event_record(h->ev0, h->stream));
+    const int max_reps = (h->max_iter + 1 + G - 1) / G + 2;
+    bool all_done = false;
+    for (int rep = 0; rep < max_reps && !all_done; ++rep) {
+        if (use_graph) RTCHECK(rt::graph_launch(h->graph, h->stream));
+        else for (int it = 0; it < G; ++it) RTCHECK(launch_iteration(h, false, it & 1, 0));
+        RTCHECK(launch_group(MODE_FINALIZE, make_args(h, false, 0, 0), h->stream));
+        RTCHECK(rt::d2h(h->h_ctl.data(), h->d_ctl, B * sizeof(Ctl), h->stream));
+        RTCHECK(rt::sync(h->stream));
+        all_done = true;
+        for (const Ctl &c : h->h_ctl) all_done = all_done && c.done;
+    }
+    RTCHECK(rt::event_record(h->ev1, h->stream));
+    RTCHECK(rt::sync(h->stream));
+    float ms = 0.f;
+    RTCHECK(rt::event_elapsed(&ms, h->ev0, h->ev1));
+    if (!all_done) return fail(SPOCK_ERR_HIP, "driver did not terminate (internal error)");
+    // the persistent state of every instance lives in buffer 0 between solves
+    int evals = 0;
+    for (size_t b = 0; b < B; ++b) {
+        const Ctl &c = h->h_ctl[b];
+        if (c.result_parity == 1) {
+            RTCHECK(rt::d2d(h->d_z[0] + b * dm.nz, h->d_z[1] + b * dm.nz, sizeof(double) * dm.nz, h->stream));
+            RTCHECK(rt::d2d(h->d_v[0] + b * dm.nv, h->d_v[1] + b * dm.nv, sizeof(double) * dm.nv, h->stream));
+        }
+        if (c.evals > evals) evals = c.evals;
+        if (results) {
+            spock_result_t &r = results[b];
+            r.status = c.status; r.iterations = c.evals; r.iter_ref = c.iter; r.reserved = 0;
+            r.xi1 = c.xi1; r.xi2 = c.xi2; r.xi = c.xi; r.solve_ms = ms;
+        }
+    }
+    RTCHECK(rt::sync(h->stream));
+    h->last_ms = ms;
+    h->last_iters = evals;
+    return SPOCK_OK;
+}
+
+int spock_get_z(spock_handle_t h, double *z_out) {
+    if (!h || !z_out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    RTCHECK(rt::d2h(z_out, h->d_z[0], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
+    RTCHECK(rt::sync(h->stream));
+    return SPOCK_OK;
+}
+int spock_get_v(spock_handle_t h, double *v_out) {
+    if (!h || !v_out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    RTCHECK(rt::d2h(v_out, h->d_v[0], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
+    RTCHECK(rt::sync(h->stream));
+    return SPOCK_OK;
+}
+int spock_set_state(spock_handle_t h, const double *z, const double *v) {
+    if (!h || !z || !v) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    RTCHECK(rt::h2d(h->d_z[0], z, (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
+    RTCHECK(rt::h2d(h->d_v[0], v, (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
+    RTCHECK(rt::sync(h->stream));
+    return SPOCK_OK;
+}
+int spock_reset(spock_handle_t h) {
+    if (!h) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    for (int k = 0; k < 2; ++k) {
+        RTCHECK(rt::dzero(h->d_z[k], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
+        RTCHECK(rt::dzero(h->d_v[k], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
+    }
+    RTCHECK(rt::sync(h->stream));
+    return SPOCK_OK;
+}
+
+int spock_get_history(spock_handle_t h, int32_t inst, double *xi, double *xi1, double *xi2, int32_t *backtrack, int32_t cap, int32_t *len) {
+    if (!h || inst < 0 || inst >= h->batch) return fail(SPOCK_ERR_BAD_ARG, "bad instance");
+    const int cnt = h->h_ctl[inst].evals < h->hist_cap ? h->h_ctl[inst].evals : h->hist_cap;
+    if (len) *len = cnt;
+    const int k = cnt < cap ? cnt : cap;
+    if (k <= 0) return SPOCK_OK;
+    std::vector<double> tmp((size_t)k * kHistStride);
+    RTCHECK(rt::d2h(tmp.data(), h->d_hist + (size_t)inst * h->hist_cap * kHistStride, tmp.size() * sizeof(double), h->stream));
+    RTCHECK(rt::sync(h->stream));
+    for (int i = 0; i < k; ++i) {
+        if (xi) xi[i] = tmp[(size_t)i * kHistStride + 0];
+        if (xi1) xi1[i] = tmp[(size_t)i * kHistStride + 1];
+        if (xi2) xi2[i] = tmp[(size_t)i * kHistStride + 2];
+        if (backtrack) backtrack[i] = (int32_t)tmp[(size_t)i * kHistStride + 3];
+    }
+    return SPOCK_OK;
+}
+
+// ---- operator-level entry points: the fused kernels driven with inputs that isolate one operator ----
+int spock_op_L(spock_handle_t h, const double *z, double *v_out) {
+    if (!h || !z || !v_out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    // phase B with w = zbar, no prox: v_out = 1 * L z + 0
+    return run_op(h, nullptr, nullptr, z, nullptr, 1., 1., F_NO_ALOCAL | F_NO_SWEEP | F_W_IS_ZBAR | F_NO_PROX, false, true, nullptr, v_out);
+}
+int spock_op_Lt(spock_handle_t h, const double *v, double *z_out) {
+    if (!h || !v || !z_out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    // phase A raw with gamma = -1 and z = 0: z_out = 1 * L'v + 0
+    return run_op(h, nullptr, v, nullptr, nullptr, -1., 1., F_RAW_LT | F_NO_SWEEP | F_NO_BLOCAL, true, false, z_out, nullptr);
+}
+int spock_op_prox_f(spock_handle_t h, const double *x0, double gamma, double *arg) {
+    if (!h || !x0 || !arg) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    // phase A + sweeps with v = 0: z - gamma L'0 = z exactly
+    return run_op(h, arg, nullptr, nullptr, x0, gamma, 1., F_NO_BLOCAL, true, true, arg, nullptr);
+}
+int spock_op_prox_h_conj(spock_handle_t h, double sigma, double *arg) {
+    if (!h || !arg) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    // phase B with z = zbar = 0: v + sigma L 0 = v exactly
+    return run_op(h, nullptr, arg, nullptr, nullptr, 1., sigma, F_NO_ALOCAL | F_NO_SWEEP, false, true, nullptr, arg);
+}
+int spock_op_T(spock_handle_t h, const double *x0, const double *z, const double *v, double gamma, double sigma, double *zbar_out, double *vbar_out) {
+    if (!h || !x0 || !z || !v || !zbar_out || !vbar_out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    return run_op(h, z, v, nullptr, x0, gamma, sigma, 0, true, true, zbar_out, vbar_out);
+}
+int spock_op_dot(spock_handle_t h, const double *a_z, const double *a_v, const double *b_z, const double *b_v, double gamma, double sigma, double *out) {
+    if (!h || !a_z || !a_v || !b_z || !b_v || !out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    // <a, P b>, P = [[I, -gamma L'], [-sigma L, I]] (implicit_l.jl:485-516): L b_z and L' b_v on the device,
+    // the two inner products in the reference's sequential order on the host.
+    const Dims &dm = h->bp.dm;
+    std::vector<double> Lv(dm.nv), Lz(dm.nz);
+    int e = spock_op_L(h, b_z, Lv.data());
+    if (e) return e;
+    e = spock_op_Lt(h, b_v, Lz.data());
+    if (e) return e;
+    double res = 0.;
+    for (int k = 0; k < dm.nz; ++k) res += a_z[k] * (b_z[k] - gamma * Lz[k]);
+    for (int k = 0; k < dm.nv; ++k) res += a_v[k] * (-sigma * Lv[k] + b_v[k]);
+    *out = res;
+    return SPOCK_OK;
+}
+
+int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_t cap, int32_t *len) {
+    if (!h) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    const std::vector<double> *src = nullptr;
+    switch (which) {
+        case 0: src = &h->bp.P; break;
+        case 1: src = &h->bp.K; break;
+        case 2: src = &h->bp.Rinv; break;
+        case 3: src = &h->bp.ABK; break;
+        case 4: src = &h->bp.ls; break;
+        case 5: src = &h->bp.sqrtQ; break;
+        case 6: src = &h->bp.sqrtR; break;
+        case 7: src = &h->bp.sqrtQN; break;
+        default: return fail(SPOCK_ERR_BAD_ARG, "unknown build product");
+    }
+    if (len) *len = (int32_t)src->size();
+    if (out) { const size_t k = src->size() < (size_t)cap ? src->size() : (size_t)cap; std::memcpy(out, src->data(), k * sizeof(double)); }
+    return SPOCK_OK;
+}
+
+int spock_get_timing(spock_handle_t h, double *iter_ms_avg, int32_t *iters_timed) {
+    if (!h) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    if (iter_ms_avg) *iter_ms_avg = h->last_iters > 0 ? h->last_ms / h->last_iters : 0.;
+    if (iters_timed) *iters_timed = h->last_iters;
+    return SPOCK_OK;
+}
+
+}  // extern "C"

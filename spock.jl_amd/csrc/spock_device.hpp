@@ -1,0 +1,598 @@
+// spock_device.hpp -- the per-thread bodies of the fused Chambolle-Pock kernels.
+//
+// One thread owns one NON-LEAF tree node i together with the edge quantities of its d children
+// (and, when the children are leaves, the leaves themselves).  With that ownership every piece of the
+// CP operator T(z, v) = (prox_f(z - gamma L'v), prox_h*(v + sigma L(2 zbar - z))) except the S1 tree
+// sweep is thread-local:
+//   phase A  a_local   : zbar0 = z - gamma L'v on the owned entries  (L_transpose!, implicit_l.jl:320-449)
+//                        + risk-kernel projection S2                 (projection_S2!, implicit_l.jl:688-727)
+//   sweep    bwd_level : Riccati-style backward recursion of S1      (projection_S1!, implicit_l.jl:584-637)
+//            fwd_level : forward roll-out                            (implicit_l.jl:667-681)
+//   phase B  b_local   : L(2 zbar - z) (L!, implicit_l.jl:177-318), Moreau step around the cone / box
+//                        projections (prox_h_conj!, implicit_l.jl:911-951, :752-909,
+//                        risk_measures.jl:14-71, constraints.jl:24-54) and the residuals of
+//                        should_terminate! (cp.jl:54-123)
+// The sweeps exchange q (child -> parent) and x (parent -> child) through LDS between tree levels.
+//
+// This header compiles for gfx950 (included by spock_kernels.hip) and, with SPOCK_HOST_EMU defined,
+// as plain C++ for the CPU-side debugging harness under tests/emu (never part of the product).
+#pragma once
+#include <cmath>
+
+#include "spock_internal.hpp"
+
+#ifdef SPOCK_HOST_EMU
+#define SPK_DEV inline
+#define SPK_UNROLL
+#else
+#define SPK_DEV __device__ __forceinline__
+#define SPK_UNROLL _Pragma("unroll P::UNR")
+#endif
+
+namespace spock {
+
+template <int NX, int NU, int D, int NY>
+struct StaticDims {
+    static constexpr int MAXNX = NX, MAXNU = NU, MAXD = D, MAXNY = NY, MAXM = NY + 2 * D, UNR = 128;
+    SPK_DEV explicit StaticDims(const Dims &) {}
+    SPK_DEV constexpr int nx() const { return NX; }
+    SPK_DEV constexpr int nu() const { return NU; }
+    SPK_DEV constexpr int d() const { return D; }
+    SPK_DEV constexpr int ny() const { return NY; }
+};
+struct DynDims {
+    static constexpr int MAXNX = kDynMaxNx, MAXNU = kDynMaxNu, MAXD = kDynMaxD, MAXNY = kDynMaxNy,
+                         MAXM = kDynMaxNy + 2 * kDynMaxD, UNR = 1;
+    int nx_, nu_, d_, ny_;
+    SPK_DEV explicit DynDims(const Dims &dm) : nx_(dm.nx), nu_(dm.nu), d_(dm.d), ny_(dm.ny) {}
+    SPK_DEV int nx() const { return nx_; }
+    SPK_DEV int nu() const { return nu_; }
+    SPK_DEV int d() const { return d_; }
+    SPK_DEV int ny() const { return ny_; }
+};
+
+// Per-thread state that lives across the phases of one kernel (registers on the GPU).
+template <class P>
+struct TState {
+    int lvl, pos, node, c0;   // level and position inside the group, global node, first child
+    bool active;
+    bool kids_leaf;           // children are leaves of the TREE (this thread also owns them)
+    bool kids_gleaf;          // children are leaves of the GROUP (crown: the subtree roots)
+    double xb[P::MAXNX];      // xbar_i (phase A)  -> x_i (after the forward sweep)
+    double ub[P::MAXNU];      // ubar_i            -> u_i
+    double dd[P::MAXNU];      // d_i of the Riccati recursion
+    double xl[P::MAXD][P::MAXNX];  // leaf children: xbar_j -> x_j
+};
+
+SPK_DEV double spk_max_nan(double m, double a) { return (a > m || a != a) ? a : m; }  // NaN-propagating max
+SPK_DEV double spk_clamp(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
+
+// event of child slot c: w = (j % d) + 1 with j = 2 + (i-1) d + c, 1-based (scenario_tree.jl:77)
+SPK_DEV int slot_event(int c, int d) { return (2 + c) % d; }
+
+// (t; x) second-order-cone projection, MOI ordering t first (risk_measures.jl:47-71)
+template <int MAXLEN>
+SPK_DEV void project_soc(double *vec, int len) {
+    double t = vec[0], s = 0.;
+    for (int i = 1; i < len; ++i) s += vec[i] * vec[i];
+    double x_norm = sqrt(s);
+    if (x_norm <= t) {
+    } else if (x_norm <= -t) {
+        for (int k = 0; k < len; ++k) vec[k] = 0.;
+    } else {
+        double t2 = (t + x_norm) / 2.;
+        vec[0] = t2;
+        for (int k = 1; k < len; ++k) vec[k] = t2 * vec[k] / x_norm;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// group geometry: thread tau <-> local BFS index tau of a complete d-ary group tree
+template <class P>
+SPK_DEV void init_geometry(const P &p, const Dims &dm, int tau, int root_stage, int root_pos, int stages, bool crown,
+                           TState<P> &s) {
+    const int d = p.d();
+    int lvl = 0, first = 0, cnt = 1;
+    while (lvl < stages - 1 && tau >= first + cnt) { first += cnt; cnt *= d; ++lvl; }
+    s.active = (lvl < stages - 1);
+    s.lvl = lvl;
+    s.pos = tau - first;
+    if (!s.active) { s.pos = 0; s.lvl = 0; }
+    int span = 1;
+    for (int k = 0; k < s.lvl; ++k) span *= d;
+    s.node = dm.first[root_stage + s.lvl] + root_pos * span + s.pos;
+    s.c0 = s.node * d + 1;
+    s.kids_gleaf = s.active && (s.lvl == stages - 2);
+    s.kids_leaf = s.kids_gleaf && !crown && (root_stage + stages == dm.N);
+    if (crown) s.kids_leaf = false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase A, node-local:  zbar0 = (-gamma) L'v + z on the entries owned by node i, then S2.
+template <class P>
+SPK_DEV void a_local(const P &p, const Dims &dm, const double *M, const double *z, const double *v, double *zo,
+                     TState<P> &s, double gamma, unsigned flags) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
+    const int i = s.node, nxu = nx + nu;
+    const double mg = -gamma;
+    const bool raw = (flags & F_RAW_LT) != 0;
+    // x_i <- Gamma' v7 + sum_j sqrtQ_j v3_j  (implicit_l.jl:351-373)
+    {
+        double acc[P::MAXNX];
+        SPK_UNROLL for (int k = 0; k < nx; ++k) acc[k] = v[dm.o7 + i * nxu + k];
+        SPK_UNROLL for (int c = 0; c < d; ++c) {
+            const int jn = s.c0 + c - 1;
+            const double *SQ = M + dm.mSqQ + (dm.nQ == 1 ? 0 : jn) * nx * nx;
+            const double *v3 = v + dm.o3 + jn * nx;
+            SPK_UNROLL for (int r = 0; r < nx; ++r) {
+                double t = 0.;
+                SPK_UNROLL for (int k = 0; k < nx; ++k) t += SQ[r + k * nx] * v3[k];
+                acc[r] += t;
+            }
+        }
+        SPK_UNROLL for (int k = 0; k < nx; ++k) s.xb[k] = mg * acc[k] + z[dm.zx + i * nx + k];
+    }
+    // u_i <- Gamma' v7 + sum_j sqrtR_j v4_j  (implicit_l.jl:399-420)
+    {
+        double acc[P::MAXNU];
+        SPK_UNROLL for (int k = 0; k < nu; ++k) acc[k] = v[dm.o7 + i * nxu + nx + k];
+        SPK_UNROLL for (int c = 0; c < d; ++c) {
+            const int jn = s.c0 + c - 1;
+            const double *SR = M + dm.mSqR + (dm.nR == 1 ? 0 : jn) * nu * nu;
+            const double *v4 = v + dm.o4 + jn * nu;
+            SPK_UNROLL for (int r = 0; r < nu; ++r) {
+                double t = 0.;
+                SPK_UNROLL for (int k = 0; k < nu; ++k) t += SR[r + k * nu] * v4[k];
+                acc[r] += t;
+            }
+        }
+        SPK_UNROLL for (int k = 0; k < nu; ++k) s.ub[k] = mg * acc[k] + z[dm.zu + i * nu + k];
+    }
+    // [y_i ; s_children ; tau_children]  (implicit_l.jl:423-448)
+    double vec[P::MAXM];
+    const double v2i = v[dm.o2 + i];
+    const double *bb = M + dm.mb;
+    SPK_UNROLL for (int k = 0; k < ny; ++k) vec[k] = mg * (v[i * ny + k] - bb[k] * v2i) + z[dm.zy + i * ny + k];
+    SPK_UNROLL for (int c = 0; c < d; ++c) {
+        const int j = s.c0 + c;
+        double ls;
+        if (j < dm.nn) ls = v[dm.o2 + j];
+        else ls = 0.5 * v[dm.o12 + (j - dm.nn)] + 0.5 * v[dm.o13 + (j - dm.nn)];
+        vec[ny + c] = mg * ls + z[dm.zs + j];
+        vec[ny + d + c] = mg * (0.5 * v[dm.o5 + j - 1] + 0.5 * v[dm.o6 + j - 1]) + z[dm.zt + j - 1];
+    }
+    // leaf children: x_j <- v14_j + sqrtQN v11_j  (implicit_l.jl:376-396)
+    if (s.kids_leaf) {
+        SPK_UNROLL for (int c = 0; c < d; ++c) {
+            const int j = s.c0 + c, li = j - dm.nn;
+            const double *SN = M + dm.mSqQN + (dm.nQN == 1 ? 0 : li) * nx * nx;
+            const double *v11 = v + dm.o11 + li * nx;
+            SPK_UNROLL for (int r = 0; r < nx; ++r) {
+                double t = 0.;
+                SPK_UNROLL for (int k = 0; k < nx; ++k) t += SN[r + k * nx] * v11[k];
+                s.xl[c][r] = mg * (v[dm.o14 + li * nx + r] + t) + z[dm.zx + j * nx + r];
+            }
+        }
+    }
+    if (raw) {  // operator L': store every owned entry as is
+        SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + i * nx + k] = s.xb[k];
+        SPK_UNROLL for (int k = 0; k < nu; ++k) zo[dm.zu + i * nu + k] = s.ub[k];
+        SPK_UNROLL for (int k = 0; k < ny; ++k) zo[dm.zy + i * ny + k] = vec[k];
+        SPK_UNROLL for (int c = 0; c < d; ++c) {
+            const int j = s.c0 + c;
+            zo[dm.zs + j] = vec[ny + c];
+            zo[dm.zt + j - 1] = vec[ny + d + c];
+            if (s.kids_leaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + j * nx + k] = s.xl[c][k]; }
+        }
+        if (i == 0) zo[dm.zs] = mg * v[dm.o2] + z[dm.zs];
+        return;
+    }
+    // s_1: (z - gamma L'v)[s_1] - gamma  (prox_f!, implicit_l.jl:741)
+    if (i == 0) zo[dm.zs] = (mg * v[dm.o2] + z[dm.zs]) - gamma;
+    // S2: projector onto ker [E' -I -I ; F' 0 0] applied to [y_i; s_ch; tau_ch]  (implicit_l.jl:708-726)
+    const int m = ny + 2 * d;
+    const double *LS = M + dm.mLs;
+    SPK_UNROLL for (int r = 0; r < m; ++r) {
+        double t = 0.;
+        SPK_UNROLL for (int k = 0; k < m; ++k) t += LS[r + k * m] * vec[k];
+        if (r < ny) zo[dm.zy + i * ny + r] = t;
+        else if (r < ny + d) zo[dm.zs + s.c0 + (r - ny)] = t;
+        else zo[dm.zt + s.c0 + (r - ny - d) - 1] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one level of the backward recursion (implicit_l.jl:584-637) for the thread's node at global stage t.
+//   ex    : LDS exchange buffer, [group non-leaf local index][nx]
+//   qg    : global q of the group leaves when they are subtree roots (crown), else nullptr
+//   q_out : where the group root's q goes (subtree -> global), or nullptr
+template <class P>
+SPK_DEV void bwd_node(const P &p, const Dims &dm, const double *M, int t, int tau, double *ex, const double *qg,
+                      double *q_out, TState<P> &s) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d();
+    double qc[P::MAXD][P::MAXNX];
+    SPK_UNROLL for (int c = 0; c < d; ++c) {
+        if (s.kids_leaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[c][k] = -s.xl[c][k]; }   // q_leaf = -xbar_leaf (:578-582)
+        else if (s.kids_gleaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[c][k] = qg[(s.pos * d + c) * nx + k]; }
+        else { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[c][k] = ex[(tau * d + 1 + c) * nx + k]; }
+    }
+    // d_i = Rtilde^-1 (ubar_i - sum_j B_w' q_j)   (:586-604)
+    double rhs[P::MAXNU];
+    SPK_UNROLL for (int k = 0; k < nu; ++k) rhs[k] = 0.;
+    SPK_UNROLL for (int c = 0; c < d; ++c) {
+        const double *Bw = M + dm.mB + slot_event(c, d) * nx * nu;
+        SPK_UNROLL for (int col = 0; col < nu; ++col) {
+            double t1 = 0.;
+            SPK_UNROLL for (int r = 0; r < nx; ++r) t1 += Bw[r + col * nx] * qc[c][r];
+            rhs[col] += t1;
+        }
+    }
+    SPK_UNROLL for (int k = 0; k < nu; ++k) rhs[k] = s.ub[k] - rhs[k];
+    const double *Ri = M + dm.mRinv + t * nu * nu;
+    SPK_UNROLL for (int r = 0; r < nu; ++r) {
+        double t1 = 0.;
+        SPK_UNROLL for (int k = 0; k < nu; ++k) t1 += Ri[r + k * nu] * rhs[k];
+        s.dd[r] = t1;
+    }
+    // q_i = sum_j ABK_j' (P_j B_w d_i + q_j) + K_i' (d_i - ubar_i) - xbar_i   (:606-636)
+    double qi[P::MAXNX];
+    SPK_UNROLL for (int k = 0; k < nx; ++k) qi[k] = 0.;
+    const double *Pc = M + dm.mP + (t + 1) * nx * nx;
+    SPK_UNROLL for (int c = 0; c < d; ++c) {
+        const double *Bw = M + dm.mB + slot_event(c, d) * nx * nu;
+        const double *Ab = M + dm.mABK + ((t + 1) * d + c) * nx * nx;
+        double t1[P::MAXNX], t2[P::MAXNX];
+        SPK_UNROLL for (int r = 0; r < nx; ++r) {
+            double a = 0.;
+            SPK_UNROLL for (int k = 0; k < nu; ++k) a += Bw[r + k * nx] * s.dd[k];
+            t1[r] = a;
+        }
+        SPK_UNROLL for (int r = 0; r < nx; ++r) {
+            double a = 0.;
+            SPK_UNROLL for (int k = 0; k < nx; ++k) a += Pc[r + k * nx] * t1[k];
+            t2[r] = a + qc[c][r];
+        }
+        SPK_UNROLL for (int col = 0; col < nx; ++col) {
+            double a = 0.;
+            SPK_UNROLL for (int r = 0; r < nx; ++r) a += Ab[r + col * nx] * t2[r];
+            qi[col] += a;
+        }
+    }
+    const double *Kt = M + dm.mK + t * nu * nx;
+    SPK_UNROLL for (int col = 0; col < nx; ++col) {
+        double a = 0.;
+        SPK_UNROLL for (int r = 0; r < nu; ++r) a += Kt[r + col * nu] * (s.dd[r] - s.ub[r]);
+        qi[col] += a;
+    }
+    SPK_UNROLL for (int k = 0; k < nx; ++k) qi[k] -= s.xb[k];
+    if (s.lvl > 0) { SPK_UNROLL for (int k = 0; k < nx; ++k) ex[tau * nx + k] = qi[k]; }
+    else if (q_out) { SPK_UNROLL for (int k = 0; k < nx; ++k) q_out[k] = qi[k]; }
+}
+
+// one level of the forward roll-out (implicit_l.jl:667-681).  xroot: x of the group root (x0 or the
+// value the crown stored), zo: zbar, receives x_i, u_i (and the children's x where they are group leaves).
+template <class P>
+SPK_DEV void fwd_node(const P &p, const Dims &dm, const double *M, int t, int tau, double *ex, const double *xroot,
+                      double *zo, TState<P> &s) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d();
+    double xi[P::MAXNX];
+    if (s.lvl == 0) { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = xroot[k]; }
+    else { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = ex[tau * nx + k]; }
+    const double *Kt = M + dm.mK + t * nu * nx;
+    SPK_UNROLL for (int r = 0; r < nu; ++r) {
+        double a = 0.;
+        SPK_UNROLL for (int k = 0; k < nx; ++k) a += Kt[r + k * nu] * xi[k];
+        s.ub[r] = a + s.dd[r];
+    }
+    SPK_UNROLL for (int c = 0; c < d; ++c) {
+        const double *Bw = M + dm.mB + slot_event(c, d) * nx * nu;
+        const double *Ab = M + dm.mABK + ((t + 1) * d + c) * nx * nx;
+        const int j = s.c0 + c;
+        SPK_UNROLL for (int r = 0; r < nx; ++r) {
+            double a = 0., b2 = 0.;
+            SPK_UNROLL for (int k = 0; k < nx; ++k) a += Ab[r + k * nx] * xi[k];
+            SPK_UNROLL for (int k = 0; k < nu; ++k) b2 += Bw[r + k * nx] * s.dd[k];
+            const double xc = a + b2;
+            if (s.kids_leaf) { s.xl[c][r] = xc; zo[dm.zx + j * nx + r] = xc; }
+            else if (s.kids_gleaf) zo[dm.zx + j * nx + r] = xc;
+            else ex[(tau * d + 1 + c) * nx + r] = xc;
+        }
+    }
+    SPK_UNROLL for (int k = 0; k < nx; ++k) { s.xb[k] = xi[k]; zo[dm.zx + s.node * nx + k] = xi[k]; }
+    SPK_UNROLL for (int k = 0; k < nu; ++k) zo[dm.zu + s.node * nu + k] = s.ub[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase B, node-local.  zb = zbar (x_i, u_i and the leaf x_j come from the thread state unless
+// F_NO_SWEEP), z/v = the input iterate, vo = vbar.  mx[0..2] accumulate |xi_1|, |xi_2|, |xi| maxima.
+struct ProxScal {
+    double sigma, inv_sigma_neg, inv_gamma_neg;  // -1/sigma, -1/gamma as the reference forms them (cp.jl:73-75)
+    bool want_xi;                                // LOG-mode CP: xi = xi_1 + L' xi_2 (cp.jl:83-86)
+};
+
+template <class P>
+SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *z, const double *v, const double *zb,
+                     double *vo, TState<P> &s, const ProxScal &ps, unsigned flags, double *mx) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
+    const int i = s.node, nxu = nx + nu;
+    const double sg = ps.sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
+    const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0, wx = ps.want_xi;
+    double m1 = mx[0], m2 = mx[1], m3 = mx[2];
+    if (flags & F_NO_SWEEP) {
+        SPK_UNROLL for (int k = 0; k < nx; ++k) s.xb[k] = zb[dm.zx + i * nx + k];
+        SPK_UNROLL for (int k = 0; k < nu; ++k) s.ub[k] = zb[dm.zu + i * nu + k];
+        if (s.kids_leaf) {
+            SPK_UNROLL for (int c = 0; c < d; ++c) {
+                SPK_UNROLL for (int k = 0; k < nx; ++k) s.xl[c][k] = zb[dm.zx + (s.c0 + c) * nx + k];
+            }
+        }
+    }
+    // w = 2 zbar - z (cp.jl:23-24) and dz = zbar - z on x_i, u_i
+    double wxv[P::MAXNX], dzx[P::MAXNX], wuv[P::MAXNU], dzu[P::MAXNU];
+    SPK_UNROLL for (int k = 0; k < nx; ++k) {
+        const double zi = z[dm.zx + i * nx + k];
+        wxv[k] = wz ? s.xb[k] : 2. * s.xb[k] + -1. * zi;
+        dzx[k] = s.xb[k] - zi;
+    }
+    SPK_UNROLL for (int k = 0; k < nu; ++k) {
+        const double zi = z[dm.zu + i * nu + k];
+        wuv[k] = wz ? s.ub[k] : 2. * s.ub[k] + -1. * zi;
+        dzu[k] = s.ub[k] - zi;
+    }
+    // accumulators of (L' dv) and (L' xi_2) on x_i, u_i
+    double ltx[P::MAXNX], ltu[P::MAXNU], lxx[P::MAXNX], lxu[P::MAXNU];
+
+    // ---- v1, v2 : risk-measure block of node i -------------------------------------------------
+    {
+        const double *bb = M + dm.mb;
+        double wy[P::MAXNY], dzy[P::MAXNY], t1[P::MAXNY], pr[P::MAXNY];
+        double bw = 0., bdz = 0.;
+        SPK_UNROLL for (int k = 0; k < ny; ++k) {
+            const double zbk = zb[dm.zy + i * ny + k], zk = z[dm.zy + i * ny + k];
+            wy[k] = wz ? zbk : 2. * zbk + -1. * zk;
+            dzy[k] = zbk - zk;
+            bw += bb[k] * wy[k];
+            bdz += bb[k] * dzy[k];
+        }
+        const double zbs = zb[dm.zs + i], zs_ = z[dm.zs + i];
+        const double ws = wz ? zbs : 2. * zbs + -1. * zs_, dzs = zbs - zs_;
+        // v1 = y, v2 = s - b'y  (implicit_l.jl:208-222)
+        SPK_UNROLL for (int k = 0; k < ny; ++k) t1[k] = sg * wy[k] + v[i * ny + k];
+        double t2 = sg * (ws - bw) + v[dm.o2 + i];
+        double nv2;
+        if (noprox) {
+            SPK_UNROLL for (int k = 0; k < ny; ++k) pr[k] = t1[k];
+            nv2 = t2;
+        } else {
+            SPK_UNROLL for (int k = 0; k < ny; ++k) { t1[k] = t1[k] / sg; pr[k] = t1[k]; }
+            // projection onto the dual cone, sub-cone by sub-cone (implicit_l.jl:833-845)
+            int off = 0;
+            for (int cn = 0; cn < dm.n_cones; ++cn) {
+                const int kind = dm.cone_kind[cn], dim = dm.cone_dim[cn];
+                if (kind == 0) { for (int k = 0; k < dim; ++k) pr[off + k] = 0.; }
+                else if (kind == 1) { for (int k = 0; k < dim; ++k) if (pr[off + k] < 0.) pr[off + k] = 0.; }
+                else if (kind == 2) { for (int k = 0; k < dim; ++k) if (pr[off + k] > 0.) pr[off + k] = 0.; }
+                else if (kind == 4) project_soc<P::MAXNY>(pr + off, dim);
+                off += dim;
+            }
+            SPK_UNROLL for (int k = 0; k < ny; ++k) pr[k] = sg * (t1[k] - pr[k]);
+            t2 = t2 / sg;
+            const double p2 = t2 >= 0. ? t2 : 0.;   // implicit_l.jl:849-851
+            nv2 = sg * (t2 - p2);
+        }
+        const double dv2 = nv2 - v[dm.o2 + i];
+        const double x2 = (dzs - bdz) + nis * dv2;          // xi_2 on v2
+        m2 = spk_max_nan(m2, fabs(x2));
+        vo[dm.o2 + i] = nv2;
+        SPK_UNROLL for (int k = 0; k < ny; ++k) {
+            const double dv1 = pr[k] - v[i * ny + k];
+            vo[i * ny + k] = pr[k];
+            const double x2k = dzy[k] + nis * dv1;          // xi_2 on v1
+            m2 = spk_max_nan(m2, fabs(x2k));
+            const double x1k = (dv1 - bb[k] * dv2) + nig * dzy[k];   // xi_1 on y (implicit_l.jl:423-429)
+            m1 = spk_max_nan(m1, fabs(x1k));
+            if (wx) m3 = spk_max_nan(m3, fabs((x2k - bb[k] * x2) + x1k));
+        }
+        const double x1s = dv2 + nig * dzs;                 // xi_1 on s_i (implicit_l.jl:440-442)
+        m1 = spk_max_nan(m1, fabs(x1s));
+        if (wx) m3 = spk_max_nan(m3, fabs(x2 + x1s));
+    }
+    // ---- v7 : box on (x_i, u_i)  (implicit_l.jl:275-282, constraints.jl:38-54) ---------------------
+    {
+        SPK_UNROLL for (int k = 0; k < nxu; ++k) {
+            const bool isx = k < nx;
+            const double wv = isx ? wxv[k] : wuv[k - nx];
+            const double dzv = isx ? dzx[k] : dzu[k - nx];
+            const double vin = v[dm.o7 + i * nxu + k];
+            double t = sg * wv + vin, nvv;
+            if (noprox) nvv = t;
+            else {
+                t = t / sg;
+                const double pj = isx ? spk_clamp(t, dm.x_min, dm.x_max) : spk_clamp(t, dm.u_min, dm.u_max);
+                nvv = sg * (t - pj);
+            }
+            vo[dm.o7 + i * nxu + k] = nvv;
+            const double dv = nvv - vin;
+            const double x2 = dzv + nis * dv;
+            m2 = spk_max_nan(m2, fabs(x2));
+            if (isx) { ltx[k] = dv; lxx[k] = x2; } else { ltu[k - nx] = dv; lxu[k - nx] = x2; }
+        }
+    }
+    // ---- per child j: (v6_j; v3_j, v4_j, v5_j) in SOC(nx+nu+2)  (implicit_l.jl:226-272, :854-900) ---
+    SPK_UNROLL for (int c = 0; c < d; ++c) {
+        const int j = s.c0 + c, jn = j - 1;
+        const double *SQ = M + dm.mSqQ + (dm.nQ == 1 ? 0 : jn) * nx * nx;
+        const double *SR = M + dm.mSqR + (dm.nR == 1 ? 0 : jn) * nu * nu;
+        double tt[P::MAXNX + P::MAXNU + 2], pj[P::MAXNX + P::MAXNU + 2], lz[P::MAXNX + P::MAXNU + 2];
+        // tt/pj ordering = the reference's workspace: [v6, v3.., v4.., v5]; lz = L dz on the same entries
+        const double zbt = zb[dm.zt + jn], zt_ = z[dm.zt + jn];
+        const double wt = wz ? zbt : 2. * zbt + -1. * zt_, dzt = zbt - zt_;
+        tt[0] = sg * (0.5 * wt) + v[dm.o6 + jn];
+        lz[0] = 0.5 * dzt;
+        SPK_UNROLL for (int r = 0; r < nx; ++r) {
+            double a = 0., b2 = 0.;
+            SPK_UNROLL for (int k = 0; k < nx; ++k) { a += SQ[r + k * nx] * wxv[k]; b2 += SQ[r + k * nx] * dzx[k]; }
+            tt[1 + r] = sg * a + v[dm.o3 + jn * nx + r];
+            lz[1 + r] = b2;
+        }
+        SPK_UNROLL for (int r = 0; r < nu; ++r) {
+            double a = 0., b2 = 0.;
+            SPK_UNROLL for (int k = 0; k < nu; ++k) { a += SR[r + k * nu] * wuv[k]; b2 += SR[r + k * nu] * dzu[k]; }
+            tt[1 + nx + r] = sg * a + v[dm.o4 + jn * nu + r];
+            lz[1 + nx + r] = b2;
+        }
+        tt[1 + nxu] = sg * (0.5 * wt) + v[dm.o5 + jn];
+        lz[1 + nxu] = 0.5 * dzt;
+        const int len = nxu + 2;
+        if (noprox) {
+            SPK_UNROLL for (int k = 0; k < len; ++k) pj[k] = tt[k];
+        } else {
+            SPK_UNROLL for (int k = 0; k < len; ++k) tt[k] = tt[k] / sg;
+            tt[1 + nxu] -= 0.5;   // v5 -= 1/2, v6 += 1/2  (implicit_l.jl:928-933)
+            tt[0] += 0.5;
+            SPK_UNROLL for (int k = 0; k < len; ++k) pj[k] = tt[k];
+            project_soc<P::MAXNX + P::MAXNU + 2>(pj, len);
+            SPK_UNROLL for (int k = 0; k < len; ++k) pj[k] = sg * (tt[k] - pj[k]);
+        }
+        // store, residuals; tt becomes dv, lz becomes xi_2
+        vo[dm.o6 + jn] = pj[0];
+        tt[0] = pj[0] - v[dm.o6 + jn];
+        SPK_UNROLL for (int r = 0; r < nx; ++r) { vo[dm.o3 + jn * nx + r] = pj[1 + r]; tt[1 + r] = pj[1 + r] - v[dm.o3 + jn * nx + r]; }
+        SPK_UNROLL for (int r = 0; r < nu; ++r) { vo[dm.o4 + jn * nu + r] = pj[1 + nx + r]; tt[1 + nx + r] = pj[1 + nx + r] - v[dm.o4 + jn * nu + r]; }
+        vo[dm.o5 + jn] = pj[1 + nxu];
+        tt[1 + nxu] = pj[1 + nxu] - v[dm.o5 + jn];
+        SPK_UNROLL for (int k = 0; k < len; ++k) { lz[k] = lz[k] + nis * tt[k]; m2 = spk_max_nan(m2, fabs(lz[k])); }
+        // L' contributions: x_i += sqrtQ dv3, u_i += sqrtR dv4 (implicit_l.jl:365-373, :412-420)
+        SPK_UNROLL for (int r = 0; r < nx; ++r) {
+            double a = 0., b2 = 0.;
+            SPK_UNROLL for (int k = 0; k < nx; ++k) { a += SQ[r + k * nx] * tt[1 + k]; b2 += SQ[r + k * nx] * lz[1 + k]; }
+            ltx[r] += a; lxx[r] += b2;
+        }
+        SPK_UNROLL for (int r = 0; r < nu; ++r) {
+            double a = 0., b2 = 0.;
+            SPK_UNROLL for (int k = 0; k < nu; ++k) { a += SR[r + k * nu] * tt[1 + nx + k]; b2 += SR[r + k * nu] * lz[1 + nx + k]; }
+            ltu[r] += a; lxu[r] += b2;
+        }
+        // xi_1 on tau_j: 0.5 dv5 + 0.5 dv6 - dtau/gamma  (implicit_l.jl:432-437)
+        const double x1t = (0.5 * tt[1 + nxu] + 0.5 * tt[0]) + nig * dzt;
+        m1 = spk_max_nan(m1, fabs(x1t));
+        if (wx) m3 = spk_max_nan(m3, fabs((0.5 * lz[1 + nxu] + 0.5 * lz[0]) + x1t));
+
+        // ---- leaf child: (v13; v11, v12) in SOC(nx+2), v14 in the x box (implicit_l.jl:286-317, :752-810)
+        if (s.kids_leaf) {
+            const int li = j - dm.nn;
+            const double *SN = M + dm.mSqQN + (dm.nQN == 1 ? 0 : li) * nx * nx;
+            double wl[P::MAXNX], dl[P::MAXNX];
+            SPK_UNROLL for (int k = 0; k < nx; ++k) {
+                const double zk = z[dm.zx + j * nx + k];
+                wl[k] = wz ? s.xl[c][k] : 2. * s.xl[c][k] + -1. * zk;
+                dl[k] = s.xl[c][k] - zk;
+            }
+            const double zbs = zb[dm.zs + j], zs_ = z[dm.zs + j];
+            const double ws = wz ? zbs : 2. * zbs + -1. * zs_, dzs = zbs - zs_;
+            double t3[P::MAXNX + 2], p3[P::MAXNX + 2], l3[P::MAXNX + 2];   // [v13, v11.., v12]
+            t3[0] = sg * (0.5 * ws) + v[dm.o13 + li];
+            l3[0] = 0.5 * dzs;
+            SPK_UNROLL for (int r = 0; r < nx; ++r) {
+                double a = 0., b2 = 0.;
+                SPK_UNROLL for (int k = 0; k < nx; ++k) { a += SN[r + k * nx] * wl[k]; b2 += SN[r + k * nx] * dl[k]; }
+                t3[1 + r] = sg * a + v[dm.o11 + li * nx + r];
+                l3[1 + r] = b2;
+            }
+            t3[1 + nx] = sg * (0.5 * ws) + v[dm.o12 + li];
+            l3[1 + nx] = 0.5 * dzs;
+            const int l2 = nx + 2;
+            if (noprox) {
+                SPK_UNROLL for (int k = 0; k < l2; ++k) p3[k] = t3[k];
+            } else {
+                SPK_UNROLL for (int k = 0; k < l2; ++k) t3[k] = t3[k] / sg;
+                t3[1 + nx] -= 0.5;   // v12 -= 1/2, v13 += 1/2 (implicit_l.jl:934-939)
+                t3[0] += 0.5;
+                SPK_UNROLL for (int k = 0; k < l2; ++k) p3[k] = t3[k];
+                project_soc<P::MAXNX + 2>(p3, l2);
+                SPK_UNROLL for (int k = 0; k < l2; ++k) p3[k] = sg * (t3[k] - p3[k]);
+            }
+            vo[dm.o13 + li] = p3[0];
+            t3[0] = p3[0] - v[dm.o13 + li];
+            SPK_UNROLL for (int r = 0; r < nx; ++r) { vo[dm.o11 + li * nx + r] = p3[1 + r]; t3[1 + r] = p3[1 + r] - v[dm.o11 + li * nx + r]; }
+            vo[dm.o12 + li] = p3[1 + nx];
+            t3[1 + nx] = p3[1 + nx] - v[dm.o12 + li];
+            SPK_UNROLL for (int k = 0; k < l2; ++k) { l3[k] = l3[k] + nis * t3[k]; m2 = spk_max_nan(m2, fabs(l3[k])); }
+            // v14 and the x_j, s_j residuals
+            SPK_UNROLL for (int r = 0; r < nx; ++r) {
+                const double vin = v[dm.o14 + li * nx + r];
+                double t = sg * wl[r] + vin, nvv;
+                if (noprox) nvv = t;
+                else { t = t / sg; nvv = sg * (t - spk_clamp(t, dm.x_min, dm.x_max)); }
+                vo[dm.o14 + li * nx + r] = nvv;
+                const double dv = nvv - vin;
+                const double x2 = dl[r] + nis * dv;
+                m2 = spk_max_nan(m2, fabs(x2));
+                double a = 0., b2 = 0.;
+                SPK_UNROLL for (int k = 0; k < nx; ++k) { a += SN[r + k * nx] * t3[1 + k]; b2 += SN[r + k * nx] * l3[1 + k]; }
+                const double x1 = (dv + a) + nig * dl[r];     // x_leaf = v14 + sqrtQN v11 (implicit_l.jl:376-396)
+                m1 = spk_max_nan(m1, fabs(x1));
+                if (wx) m3 = spk_max_nan(m3, fabs((x2 + b2) + x1));
+            }
+            const double x1s = (0.5 * t3[1 + nx] + 0.5 * t3[0]) + nig * dzs;   // s_leaf (implicit_l.jl:445-448)
+            m1 = spk_max_nan(m1, fabs(x1s));
+            if (wx) m3 = spk_max_nan(m3, fabs((0.5 * l3[1 + nx] + 0.5 * l3[0]) + x1s));
+        }
+    }
+    // xi_1 (and xi) on x_i, u_i
+    SPK_UNROLL for (int k = 0; k < nx; ++k) {
+        const double x1 = ltx[k] + nig * dzx[k];
+        m1 = spk_max_nan(m1, fabs(x1));
+        if (wx) m3 = spk_max_nan(m3, fabs(lxx[k] + x1));
+    }
+    SPK_UNROLL for (int k = 0; k < nu; ++k) {
+        const double x1 = ltu[k] + nig * dzu[k];
+        m1 = spk_max_nan(m1, fabs(x1));
+        if (wx) m3 = spk_max_nan(m3, fabs(lxu[k] + x1));
+    }
+    mx[0] = m1; mx[1] = m2; mx[2] = m3;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Termination bookkeeping of run_cp! / should_terminate! (cp.jl:54-123, :205-228), run by ONE thread per
+// instance at the start of an iteration (for the previous one) and by the finalize kernel.
+// Returns true when the instance is finished.
+SPK_DEV bool ctl_prologue(Ctl &c, const double *partials, int n_groups, double *hist, int hist_cap, int parity,
+                          bool start_next) {
+    if (c.done) return true;
+    if (c.pending) {
+        double x1 = 0., x2 = 0., x3 = 0.;
+        for (int g = 0; g < n_groups; ++g) {
+            x1 = spk_max_nan(x1, partials[g * kPartialStride + 0]);
+            x2 = spk_max_nan(x2, partials[g * kPartialStride + 1]);
+            x3 = spk_max_nan(x3, partials[g * kPartialStride + 2]);
+        }
+        const bool log = (c.log_mode == 2);
+        double xi = NAN;
+        if (log) xi = (c.alg == 1) ? x3 : (x1 > x2 ? x1 : x2);   // cp.jl:83-86 / sp.jl:308
+        c.xi1 = x1; c.xi2 = x2; c.xi = xi;
+        if (hist && c.evals < hist_cap) {
+            double *h = hist + (long)c.evals * kHistStride;
+            h[0] = xi; h[1] = x1; h[2] = x2; h[3] = 0.;
+        }
+        c.evals += 1;
+        c.pending = 0;
+        bool term;
+        if (log) term = (xi <= c.tol);
+        else {
+            const double t1 = c.tol * c.res0[0] > c.tol ? c.tol * c.res0[0] : c.tol;   // max(tol*res_0, tol)
+            const double t2 = c.tol * c.res0[1] > c.tol ? c.tol * c.res0[1] : c.tol;
+            term = (x1 <= t1 && x2 <= t2);
+        }
+        if (c.res0[0] == -INFINITY) c.res0[0] = x1;
+        if (c.res0[1] == -INFINITY) c.res0[1] = x2;
+        if (x1 != x1 || x2 != x2) { c.done = 1; c.status = 2; c.result_parity = parity; return true; }
+        if (term) { c.done = 1; c.status = 0; c.result_parity = parity; return true; }
+        c.iter += 1;
+        if (c.iter >= c.max_iter) { c.done = 1; c.status = 1; c.result_parity = parity; return true; }
+    }
+    if (start_next) c.pending = 1;
+    return false;
+}
+
+}  // namespace spock

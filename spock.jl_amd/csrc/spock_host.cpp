@@ -1,0 +1,280 @@
+// spock_host.cpp -- host-side build step of the product: everything build_cpock / build_spock compute
+// once per problem structure (/root/reference/src/models/cpock.jl:1-163, src/models/spock.jl:1-210):
+//   * sizes and offsets              get_nz / get_nv (implicit_l.jl:5-44), cpock.jl:51-60
+//   * offline Riccati recursion      ricatti_offline (implicit_l.jl:46-97)
+//   * kernel projector               cpock.jl:71-81, :125-128
+//   * square roots of the costs      cpock.jl:119-121
+// plus the tiling of the tree into per-workgroup subtrees.  The results are packed into one matrix pool
+// that the kernels address through offsets in `Dims`.
+//
+// Because the reference's ricatti_offline only uses A_w, B_w and the (uniform) tree shape, P_i, K_i and
+// Rtilde_i depend on the STAGE of node i only and ABK_j on (stage, child slot); they are stored per stage.
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+#include "spock_internal.hpp"
+
+namespace spock {
+namespace {
+
+struct Mat {  // dense column-major
+    int r = 0, c = 0;
+    std::vector<double> a;
+    Mat() {}
+    Mat(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.) {}
+    double &operator()(int i, int j) { return a[(size_t)i + (size_t)j * r]; }
+    double operator()(int i, int j) const { return a[(size_t)i + (size_t)j * r]; }
+    static Mat from(const double *p, int r_, int c_) { Mat m(r_, c_); std::memcpy(m.a.data(), p, sizeof(double) * r_ * c_); return m; }
+    static Mat eye(int n) { Mat m(n, n); for (int i = 0; i < n; ++i) m(i, i) = 1.; return m; }
+};
+Mat T(const Mat &x) { Mat y(x.c, x.r); for (int i = 0; i < x.r; ++i) for (int j = 0; j < x.c; ++j) y(j, i) = x(i, j); return y; }
+Mat mul(const Mat &x, const Mat &y) {
+    Mat z(x.r, y.c);
+    for (int j = 0; j < y.c; ++j)
+        for (int i = 0; i < x.r; ++i) {
+            double s = 0.;
+            for (int k = 0; k < x.c; ++k) s += x(i, k) * y(k, j);
+            z(i, j) = s;
+        }
+    return z;
+}
+Mat add(const Mat &x, const Mat &y) { Mat z = x; for (size_t k = 0; k < z.a.size(); ++k) z.a[k] += y.a[k]; return z; }
+
+// symmetric eigen-decomposition by cyclic Jacobi rotations: S = V diag(w) V'
+void sym_eig(const Mat &S, Mat &V, std::vector<double> &w) {
+    const int n = S.r;
+    Mat a = S;
+    V = Mat::eye(n);
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.;
+        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += a(p, q) * a(p, q);
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a(p, q);
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (a(q, q) - a(p, p)) / (2. * apq);
+                const double t = (theta >= 0. ? 1. : -1.) / (std::fabs(theta) + std::sqrt(theta * theta + 1.));
+                const double c = 1. / std::sqrt(t * t + 1.), s = t * c;
+                for (int k = 0; k < n; ++k) { const double x = a(k, p), y = a(k, q); a(k, p) = c * x - s * y; a(k, q) = s * x + c * y; }
+                for (int k = 0; k < n; ++k) { const double x = a(p, k), y = a(q, k); a(p, k) = c * x - s * y; a(q, k) = s * x + c * y; }
+                for (int k = 0; k < n; ++k) { const double x = V(k, p), y = V(k, q); V(k, p) = c * x - s * y; V(k, q) = s * x + c * y; }
+            }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; ++i) w[i] = a(i, i);
+}
+
+// principal square root of a symmetric PSD matrix; diagonal input -> element-wise (Julia's sqrt(::Diagonal))
+Mat sym_sqrt(const Mat &S) {
+    const int n = S.r;
+    bool diag = true;
+    for (int j = 0; j < n && diag; ++j) for (int i = 0; i < n; ++i) if (i != j && S(i, j) != 0.) { diag = false; break; }
+    Mat out(n, n);
+    if (diag) { for (int i = 0; i < n; ++i) out(i, i) = std::sqrt(S(i, i)); return out; }
+    Mat V; std::vector<double> w;
+    sym_eig(S, V, w);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            double s = 0.;
+            for (int k = 0; k < n; ++k) s += V(i, k) * std::sqrt(w[k] > 0. ? w[k] : 0.) * V(j, k);
+            out(i, j) = s;
+        }
+    return out;
+}
+
+// inverse of a symmetric positive definite matrix through its Cholesky factor; false if not SPD
+bool spd_inverse(const Mat &S, Mat &inv) {
+    const int n = S.r;
+    Mat L(n, n);
+    for (int j = 0; j < n; ++j) {
+        double s = S(j, j);
+        for (int k = 0; k < j; ++k) s -= L(j, k) * L(j, k);
+        if (!(s > 0.)) return false;
+        const double dj = std::sqrt(s);
+        L(j, j) = dj;
+        for (int i = j + 1; i < n; ++i) {
+            double t = S(i, j);
+            for (int k = 0; k < j; ++k) t -= L(i, k) * L(j, k);
+            L(i, j) = t / dj;
+        }
+    }
+    inv = Mat(n, n);
+    std::vector<double> x(n);
+    for (int c = 0; c < n; ++c) {
+        for (int i = 0; i < n; ++i) {
+            double s = (i == c) ? 1. : 0.;
+            for (int k = 0; k < i; ++k) s -= L(i, k) * x[k];
+            x[i] = s / L(i, i);
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = x[i];
+            for (int k = i + 1; k < n; ++k) s -= L(k, i) * x[k];
+            x[i] = s / L(i, i);
+        }
+        for (int i = 0; i < n; ++i) inv(i, c) = x[i];
+    }
+    for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) { const double m = 0.5 * (inv(i, j) + inv(j, i)); inv(i, j) = m; inv(j, i) = m; }
+    return true;
+}
+
+int ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
+
+}  // namespace
+
+int group_threads(int d, int stages) { return stages < 2 ? 0 : (ipow(d, stages - 1) - 1) / (d - 1); }
+
+// Stage at which the tree is cut.  A group (subtree or crown) runs as ONE workgroup with one thread per
+// non-leaf node and nx doubles of LDS per thread for the q / x exchange of the S1 sweeps.
+int choose_split_stage(int N, int d, int nx) {
+    int max_thr = 512;
+    const int lds_thr = (64 * 1024 / 8) / (nx > 0 ? nx : 1);
+    if (lds_thr < max_thr) max_thr = lds_thr;
+    if (group_threads(d, N) <= max_thr) return 0;
+    int t0 = (N - 1) / 2;
+    while (t0 < N - 2 && group_threads(d, N - t0) > max_thr) ++t0;
+    if (group_threads(d, N - t0) > max_thr || group_threads(d, t0 + 1) > max_thr) return -1;
+    return t0;
+}
+
+std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported) {
+    unsupported = false;
+    const int N = hp.N, d = hp.d, nx = hp.nx, nu = hp.nu, ny = hp.ny;
+    if (d <= 1) return "Branching factor d must be larger than 1";       // scenario_tree.jl:62-64
+    if (N < 2 || N > kMaxStages) { unsupported = N > kMaxStages; return "N (stages including the root) must be in [2, 24]"; }
+    if (nx < 1 || nu < 1 || ny < 1) return "nx, nu, ny must be positive";
+    if (nx > kDynMaxNx || nu > kDynMaxNu || d > kDynMaxD || ny > kDynMaxNy) {
+        unsupported = true;
+        return "dimensions exceed this build's limits (nx, nu <= 64, d <= 4, ny <= 16)";
+    }
+    if ((int)hp.cone_kind.size() > kMaxCones) { unsupported = true; return "more than 8 sub-cones"; }
+    double nodes = (std::pow((double)d, N) - 1.) / (d - 1);
+    if (nodes * (nx + nu + ny + 8) * 3. > 2.0e9) { unsupported = true; return "tree too large for 32-bit offsets"; }
+
+    Dims &dm = out.dm;
+    std::memset(&dm, 0, sizeof(dm));
+    dm.N = N; dm.d = d; dm.nx = nx; dm.nu = nu; dm.ny = ny;
+    dm.n = (ipow(d, N) - 1) / (d - 1);
+    dm.nl = ipow(d, N - 1);
+    dm.nn = (ipow(d, N - 1) - 1) / (d - 1);
+    const int n = dm.n, nn = dm.nn, nl = dm.nl;
+    dm.zx = 0; dm.zu = n * nx; dm.zs = dm.zu + nn * nu; dm.zt = dm.zs + n; dm.zy = dm.zt + (n - 1);
+    dm.nz = dm.zy + nn * ny;
+    dm.o2 = nn * ny; dm.o3 = dm.o2 + nn; dm.o4 = dm.o3 + nx * (n - 1); dm.o5 = dm.o4 + nu * (n - 1);
+    dm.o6 = dm.o5 + (n - 1); dm.o7 = dm.o6 + (n - 1); dm.o11 = dm.o7 + nn * (nx + nu);
+    dm.o12 = dm.o11 + nl * nx; dm.o13 = dm.o12 + nl; dm.o14 = dm.o13 + nl;
+    dm.nv = dm.o14 + nl * nx;
+    dm.nQ = hp.nQ; dm.nR = hp.nR; dm.nQN = hp.nQN;
+    if (!(hp.nQ == 1 || hp.nQ == n - 1) || !(hp.nR == 1 || hp.nR == n - 1) || !(hp.nQN == 1 || hp.nQN == nl))
+        return "cost matrix counts must be 1 or n-1 / n-1 / n_leaf";
+    dm.n_cones = (int)hp.cone_kind.size();
+    int csum = 0;
+    for (int k = 0; k < dm.n_cones; ++k) {
+        const int kind = hp.cone_kind[k];
+        if (kind < 0 || kind > 4 || hp.cone_dim[k] < 0) return "invalid cone";
+        dm.cone_kind[k] = kind == 0 ? 3 : (kind == 3 ? 0 : kind);       // MOI.dual_set: Zeros <-> Reals
+        dm.cone_dim[k] = hp.cone_dim[k];
+        csum += hp.cone_dim[k];
+    }
+    if (csum != ny) return "cone dimensions must add up to length(b)";
+    dm.x_min = hp.x_min; dm.x_max = hp.x_max; dm.u_min = hp.u_min; dm.u_max = hp.u_max;
+    for (int t = 0; t <= N; ++t) dm.first[t] = (ipow(d, t) - 1) / (d - 1);
+
+    int t0 = split_stage > 0 ? split_stage : choose_split_stage(N, d, nx);
+    if (t0 < 0) { unsupported = true; return "tree does not fit the two-level subtree tiling"; }
+    if (t0 > 0) {
+        if (t0 > N - 2) return "split_stage must leave subtrees of at least two stages";
+        const int lim = (64 * 1024 / 8) / nx < 512 ? (64 * 1024 / 8) / nx : 512;
+        if (group_threads(d, N - t0) > lim || group_threads(d, t0 + 1) > lim) { unsupported = true; return "split_stage gives groups larger than one workgroup"; }
+    }
+    dm.t0 = t0;
+    dm.nsub = t0 > 0 ? ipow(d, t0) : 1;
+    dm.sub_stages = N - t0;
+
+    // ---- offline Riccati recursion (implicit_l.jl:46-97), per stage --------------------------------
+    std::vector<Mat> A(d), B(d);
+    for (int w = 0; w < d; ++w) {
+        A[w] = Mat::from(hp.A.data() + (size_t)w * nx * nx, nx, nx);
+        B[w] = Mat::from(hp.B.data() + (size_t)w * nx * nu, nx, nu);
+    }
+    std::vector<Mat> P(N), K(N - 1), Rinv(N - 1), ABK((size_t)N * d, Mat(nx, nx));
+    P[N - 1] = Mat::eye(nx);
+    for (int t = N - 2; t >= 0; --t) {
+        Mat sum_r(nu, nu), sum_k(nu, nx);
+        for (int c = 0; c < d; ++c) {
+            const int w = (2 + c) % d;
+            const Mat BtP = mul(T(B[w]), P[t + 1]);
+            sum_r = add(sum_r, mul(BtP, B[w]));
+            sum_k = add(sum_k, mul(BtP, A[w]));
+        }
+        Mat rt(nu, nu);
+        for (int j = 0; j < nu; ++j) for (int i = 0; i < nu; ++i) rt(i, j) = (i == j ? 1. : 0.) + 0.5 * (sum_r(i, j) + sum_r(j, i));
+        if (!spd_inverse(rt, Rinv[t])) return "Rtilde is not positive definite";
+        Mat negk = sum_k;
+        for (auto &x : negk.a) x = -x;
+        K[t] = mul(Rinv[t], negk);
+        Mat sum_p(nx, nx);
+        for (int c = 0; c < d; ++c) {
+            const int w = (2 + c) % d;
+            Mat abk = add(A[w], mul(B[w], K[t]));
+            sum_p = add(sum_p, mul(mul(T(abk), P[t + 1]), abk));
+            ABK[(size_t)(t + 1) * d + c] = abk;
+        }
+        P[t] = add(add(Mat::eye(nx), mul(T(K[t]), K[t])), sum_p);
+    }
+
+    // ---- projector onto ker M, M = [E' -I -I ; F' 0 0]: Pi = I - M' (M M')^+ M (cpock.jl:71-81,125-128)
+    const int m = ny + 2 * d;
+    Mat Mk(2 * d, m);
+    for (int k = 0; k < d; ++k) {
+        for (int i = 0; i < ny; ++i) { Mk(k, i) = hp.E[(size_t)i + (size_t)k * ny]; Mk(d + k, i) = hp.F[(size_t)i + (size_t)k * ny]; }
+        Mk(k, ny + k) = -1.; Mk(k, ny + d + k) = -1.;
+    }
+    Mat G = mul(Mk, T(Mk)), V;
+    std::vector<double> w;
+    sym_eig(G, V, w);
+    double wmax = 0.;
+    for (double x : w) wmax = std::fabs(x) > wmax ? std::fabs(x) : wmax;
+    Mat Gp(2 * d, 2 * d);
+    for (int k = 0; k < 2 * d; ++k) {
+        if (!(w[k] > 1e-12 * wmax)) continue;
+        for (int j = 0; j < 2 * d; ++j) for (int i = 0; i < 2 * d; ++i) Gp(i, j) += V(i, k) * V(j, k) / w[k];
+    }
+    Mat ls = Mat::eye(m), MtGM = mul(mul(T(Mk), Gp), Mk);
+    for (size_t k = 0; k < ls.a.size(); ++k) ls.a[k] -= MtGM.a[k];
+    for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { const double s = 0.5 * (ls(i, j) + ls(j, i)); ls(i, j) = s; ls(j, i) = s; }
+
+    // ---- pack -----------------------------------------------------------------------------------
+    auto &pool = out.mats;
+    pool.clear();
+    auto push = [&](const std::vector<double> &v) { int off = (int)pool.size(); pool.insert(pool.end(), v.begin(), v.end()); return off; };
+    dm.mB = (int)pool.size();
+    for (int w2 = 0; w2 < d; ++w2) push(B[w2].a);
+    dm.mK = (int)pool.size();
+    out.K.clear();
+    for (int t = 0; t < N - 1; ++t) { push(K[t].a); out.K.insert(out.K.end(), K[t].a.begin(), K[t].a.end()); }
+    dm.mRinv = (int)pool.size();
+    out.Rinv.clear();
+    for (int t = 0; t < N - 1; ++t) { push(Rinv[t].a); out.Rinv.insert(out.Rinv.end(), Rinv[t].a.begin(), Rinv[t].a.end()); }
+    dm.mP = (int)pool.size();
+    out.P.clear();
+    for (int t = 0; t < N; ++t) { push(P[t].a); out.P.insert(out.P.end(), P[t].a.begin(), P[t].a.end()); }
+    dm.mABK = (int)pool.size();
+    out.ABK.clear();
+    for (size_t k = 0; k < ABK.size(); ++k) { push(ABK[k].a); out.ABK.insert(out.ABK.end(), ABK[k].a.begin(), ABK[k].a.end()); }
+    dm.mLs = push(ls.a);
+    out.ls = ls.a;
+    dm.mb = push(hp.b);
+    out.sqrtQ.clear(); out.sqrtR.clear(); out.sqrtQN.clear();
+    dm.mSqQ = (int)pool.size();
+    for (int k = 0; k < hp.nQ; ++k) { Mat s = sym_sqrt(Mat::from(hp.Q.data() + (size_t)k * nx * nx, nx, nx)); push(s.a); out.sqrtQ.insert(out.sqrtQ.end(), s.a.begin(), s.a.end()); }
+    dm.mSqR = (int)pool.size();
+    for (int k = 0; k < hp.nR; ++k) { Mat s = sym_sqrt(Mat::from(hp.R.data() + (size_t)k * nu * nu, nu, nu)); push(s.a); out.sqrtR.insert(out.sqrtR.end(), s.a.begin(), s.a.end()); }
+    dm.mSqQN = (int)pool.size();
+    for (int k = 0; k < hp.nQN; ++k) { Mat s = sym_sqrt(Mat::from(hp.QN.data() + (size_t)k * nx * nx, nx, nx)); push(s.a); out.sqrtQN.insert(out.sqrtQN.end(), s.a.begin(), s.a.end()); }
+    for (double x : pool) if (!(x == x)) return "build step produced NaN";
+    return "";
+}
+
+}  // namespace spock

@@ -1,0 +1,109 @@
+// spock_internal.hpp -- types shared by the host build step, the kernel launchers and the C ABI.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace spock {
+
+constexpr int kMaxStages = 24;
+constexpr int kMaxCones = 8;
+// bounds of the run-time-dimension kernel variant (compile-time variants exist for the benchmark shapes)
+constexpr int kDynMaxNx = 64, kDynMaxNu = 64, kDynMaxD = 4, kDynMaxNy = 16;
+
+// Problem geometry + data layout, passed BY VALUE to every kernel.
+// z layout x|u|s|tau|y: /root/reference/src/model_dynamics/implicit_l.jl:106-158
+// v layout v1..v7,v11..v14: /root/reference/src/models/cpock.jl:51-60
+struct Dims {
+    int N, d, nx, nu, ny;
+    int n, nn, nl, nz, nv;
+    int zx, zu, zs, zt, zy;
+    int o2, o3, o4, o5, o6, o7, o11, o12, o13, o14;
+    int nQ, nR, nQN;
+    int n_cones;
+    int cone_kind[kMaxCones];  // already the DUAL cone kinds (MOI.dual_set, implicit_l.jl:841)
+    int cone_dim[kMaxCones];
+    double x_min, x_max, u_min, u_max;
+    // tree tiling: the tree is cut at stage t0 into nsub = d^t0 subtrees of sub_stages = N - t0 stages
+    // (one workgroup each) plus the crown (stages 0..t0, one workgroup).  t0 == 0: one workgroup per instance.
+    int t0, nsub, sub_stages;
+    int first[kMaxStages + 1];  // first node of each stage (scenario_tree.jl:107)
+    // offsets (in doubles) into the matrix pool
+    int mB, mK, mRinv, mP, mABK, mLs, mb, mSqQ, mSqR, mSqQN;
+};
+
+// Per-instance control block in device memory: the driver's scalars live here so that a captured
+// hipGraph can be replayed for any tol / gamma / sigma and so that kernels can stop on their own.
+struct Ctl {
+    int done;           // 1: every later kernel of this solve exits at once
+    int status;         // SPOCK_CONVERGED / SPOCK_MAX_ITER / SPOCK_NAN
+    int evals;          // termination tests run so far (= T evaluations checked)
+    int iter;           // the reference's `iter` (cp.jl:203,227)
+    int pending;        // an iteration has been issued whose termination test has not run yet
+    int result_parity;  // which of the two (z, v) buffers holds the final iterate
+    int max_iter;
+    int log_mode;       // SPOCK_LOG -> absolute xi rule (cp.jl:83-99), else res_0 rule (cp.jl:102-112)
+    int alg;
+    int pad;
+    double res0[2];     // cp.jl:114-119
+    double xi1, xi2, xi;
+    double gamma, sigma, tol;
+};
+
+constexpr int kPartialStride = 4;  // xi1, xi2, xi, unused -- per workgroup
+constexpr int kHistStride = 4;     // xi, xi1, xi2, backtrack
+
+enum KFlags : unsigned {
+    F_RAW_LT = 1u,       // phase A: write z - gamma L'v for every owned entry, no S2 / s_1 shift (operator L')
+    F_NO_SWEEP = 2u,     // skip the S1 sweeps (phase B then reads x, u from z_out)
+    F_NO_BLOCAL = 4u,    // skip phase B's node-local part (operator prox_f)
+    F_W_IS_ZBAR = 8u,    // phase B: w = zbar instead of 2 zbar - z (operator L)
+    F_NO_PROX = 16u,     // phase B: v_out = sigma L w + v, no prox (operator L)
+    F_NO_CTL = 32u,      // ignore the control block's done / pending logic (operators)
+    F_NO_ALOCAL = 64u,   // skip phase A's node-local part (operator prox_h_conj)
+};
+
+struct KArgs {
+    Dims dm;
+    const double *mats;
+    const double *z_in, *v_in;  // [batch][nz], [batch][nv]
+    double *z_out, *v_out;      // zbar, vbar
+    double *dbuf;               // [batch][nn*nu]      S1's d_i between phase A and phase B
+    double *qroot;              // [batch][nsub*nx]    S1's q at the subtree roots
+    double *partials;           // [batch][(nsub+1)*kPartialStride]
+    Ctl *ctl;                   // [batch]
+    const double *x0;           // [batch][nx]
+    double *hist;               // [batch][hist_cap*kHistStride]
+    int hist_cap;
+    int parity;
+    unsigned flags;
+    int batch;
+};
+
+enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, MODE_FINALIZE = 4 };
+
+// ---- host build step (spock_host.cpp) -------------------------------------------------------------
+struct HostProblem {
+    int N, d, nx, nu, ny;
+    std::vector<double> A, B, Q, R, QN, E, F, b;
+    int nQ, nR, nQN;
+    std::vector<int> cone_kind, cone_dim;
+    double x_min, x_max, u_min, u_max;
+};
+struct BuildProducts {
+    Dims dm;
+    std::vector<double> mats;  // the matrix pool uploaded to the device
+    // copies kept for spock_get_build_product
+    std::vector<double> P, K, Rinv, ABK, ls, sqrtQ, sqrtR, sqrtQN;
+};
+// returns "" on success, else an error message; split_stage 0 = choose
+std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported);
+int choose_split_stage(int N, int d, int nx);
+int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tree with `stages` stages
+
+// ---- kernel launchers (spock_kernels.hip) ---------------------------------------------------------
+// Each returns a hipError_t cast to int.  `stream` is a hipStream_t.
+int launch_group(int mode, const KArgs &a, void *stream);
+bool have_static_variant(int nx, int nu, int d, int ny);
+
+}  // namespace spock

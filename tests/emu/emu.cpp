@@ -1,0 +1,129 @@
+// tests/emu/emu.cpp -- HOST EMULATION HARNESS (test infrastructure, never shipped, never loaded by the
+// product package).  It compiles the very same per-thread / per-workgroup sources as the gfx950 kernels
+// (spock_device.hpp, spock_group.hpp) with SPOCK_HOST_EMU and runs the "threads" of a workgroup one after
+// the other between barriers, and it implements spock_rt.hpp on host memory, so that the whole driver in
+// spock_abi.cpp can be debugged (and run under sanitizers) on a machine without a GPU.  Linking
+// spock_abi.cpp + spock_host.cpp + this file gives tests/emu/libspock_emu.so.
+//
+// SPOCK_EMU_REVERSE=1 runs the threads of every phase in reverse order: a result that changes with the
+// order betrays a missing barrier.  SPOCK_EMU_FORCE_DYN=1 forces the run-time-dimension variant.
+#define SPOCK_HOST_EMU 1
+#include <array>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../spock.jl_amd/csrc/spock_group.hpp"
+#include "../../spock.jl_amd/csrc/spock_rt.hpp"
+
+namespace spock {
+
+static bool env_on(const char *k) { const char *e = std::getenv(k); return e && e[0] == '1'; }
+
+template <class P>
+struct EmuExec {
+    std::vector<TState<P>> st;
+    std::vector<double> ex;
+    std::vector<std::array<double, 3>> m;
+    int fl = 0, nthreads = 0;
+    bool reverse = false;
+    EmuExec(int thr, int nx) : st(thr), ex((size_t)thr * nx + 8, 0.), m(thr), nthreads(thr), reverse(env_on("SPOCK_EMU_REVERSE")) {}
+    template <class F>
+    void each(F &&f) {
+        if (!reverse) for (int t = 0; t < nthreads; ++t) f(t, st[t]);
+        else for (int t = nthreads - 1; t >= 0; --t) f(t, st[t]);
+    }
+    void barrier() {}
+    double *lds() { return ex.data(); }
+    int &flag() { return fl; }
+    void stash3(int tid, const double *mx) { m[tid] = {mx[0], mx[1], mx[2]}; }
+    void reduce3(double *dst) {
+        double r[3] = {0., 0., 0.};
+        for (int t = 0; t < nthreads; ++t) for (int k = 0; k < 3; ++k) r[k] = spk_max_nan(r[k], m[t][k]);
+        for (int k = 0; k < 3; ++k) dst[k] = r[k];
+    }
+};
+
+static inline int round64(int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; }
+
+template <class P, int MODE>
+static void run_blocks(const KArgs &a, int gx, int thr) {
+    for (int inst = 0; inst < a.batch; ++inst)
+        for (int g = 0; g < gx; ++g) {
+            EmuExec<P> x(thr, a.dm.nx);
+            group_body<P, MODE>(x, a, inst, g);
+        }
+}
+
+template <class P>
+static int launch_variant(int mode, const KArgs &a) {
+    const Dims &dm = a.dm;
+    int stages, gx;
+    switch (mode) {
+        case MODE_FULL: stages = dm.N; gx = 1; break;
+        case MODE_SUB_A: case MODE_SUB_B: stages = dm.sub_stages; gx = dm.nsub; break;
+        case MODE_CROWN: stages = dm.t0 + 1; gx = 1; break;
+        default: stages = 2; gx = 1; break;
+    }
+    const int thr = mode == MODE_FINALIZE ? 64 : round64(group_threads(dm.d, stages));
+    if (thr > 512) return 9;
+    switch (mode) {
+        case MODE_FULL: run_blocks<P, MODE_FULL>(a, gx, thr); break;
+        case MODE_SUB_A: run_blocks<P, MODE_SUB_A>(a, gx, thr); break;
+        case MODE_CROWN: run_blocks<P, MODE_CROWN>(a, gx, thr); break;
+        case MODE_SUB_B: run_blocks<P, MODE_SUB_B>(a, gx, thr); break;
+        case MODE_FINALIZE: run_blocks<P, MODE_FINALIZE>(a, gx, thr); break;
+        default: return 1;
+    }
+    return 0;
+}
+
+#define SPOCK_STATIC_SHAPES(X) X(5, 2, 2, 5) X(5, 5, 2, 5) X(2, 1, 2, 5) X(3, 2, 3, 7)
+
+bool have_static_variant(int nx, int nu, int d, int ny) {
+#define X(a, b, c, e) if (nx == a && nu == b && d == c && ny == e) return true;
+    SPOCK_STATIC_SHAPES(X)
+#undef X
+    return false;
+}
+
+int launch_group(int mode, const KArgs &a, void *) {
+    const Dims &dm = a.dm;
+    if (!env_on("SPOCK_EMU_FORCE_DYN")) {
+#define X(a_, b_, c_, e_) \
+    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_) return launch_variant<StaticDims<a_, b_, c_, e_>>(mode, a);
+        SPOCK_STATIC_SHAPES(X)
+#undef X
+    }
+    return launch_variant<DynDims>(mode, a);
+}
+
+// ---- spock_rt.hpp on host memory ---------------------------------------------------------------------
+namespace rt {
+int set_device(int) { return 0; }
+int stream_create(void **s) { *s = (void *)0x1; return 0; }
+int stream_destroy(void *) { return 0; }
+int dmalloc(void **p, size_t bytes) { *p = std::malloc(bytes ? bytes : 8); return *p ? 0 : 2; }
+int dfree(void *p) { std::free(p); return 0; }
+int dzero(void *p, size_t bytes, void *) { std::memset(p, 0, bytes); return 0; }
+int h2d(void *dst, const void *src, size_t bytes, void *) { std::memcpy(dst, src, bytes); return 0; }
+int d2h(void *dst, const void *src, size_t bytes, void *) { std::memcpy(dst, src, bytes); return 0; }
+int d2d(void *dst, const void *src, size_t bytes, void *) { std::memmove(dst, src, bytes); return 0; }
+int sync(void *) { return 0; }
+struct Ev { std::chrono::steady_clock::time_point t; };
+int event_create(void **e) { *e = new Ev(); return 0; }
+int event_destroy(void *e) { delete (Ev *)e; return 0; }
+int event_record(void *e, void *) { ((Ev *)e)->t = std::chrono::steady_clock::now(); return 0; }
+int event_elapsed(float *ms, void *e0, void *e1) {
+    *ms = std::chrono::duration<float, std::milli>(((Ev *)e1)->t - ((Ev *)e0)->t).count();
+    return 0;
+}
+bool graphs_supported() { return false; }
+int capture_begin(void *) { return 1; }
+int capture_end(void *, void **) { return 1; }
+int graph_launch(void *, void *) { return 1; }
+int graph_destroy(void *) { return 0; }
+const char *err(int code) { return code == 0 ? "ok" : (code == 9 ? "group larger than one workgroup" : "emulation runtime error"); }
+}  // namespace rt
+}  // namespace spock

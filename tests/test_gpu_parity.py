@@ -1,0 +1,183 @@
+"""GPU parity tests: the HIP path (through the C ABI, libspock_amd.so) against the CPU oracle on the same
+seeded inputs, against the reference's shipped residual trace, and -- at BASELINE.json's full sizes --
+through size-independent properties.  Tolerances (fp64): per-operator 1e-12 relative to max(1, |ref|_inf)
+(north_star asks for 1e-6 on the iterates; the operators are far tighter), CP trajectories 1e-8, the
+known-answer trace 1e-9."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = 1e-12
+
+
+def _configs(S):
+    return {
+        "car_N3": (S.get_car_fixture(), {}),                                   # the reference's own test fixture
+        "sh_N7_full": (S.get_server_heat_specs(7, 5, 2), {}),                  # KAT config, one workgroup per instance
+        "sh_N7_split3": (S.get_server_heat_specs(7, 5, 2), {"split_stage": 3}),
+        "sh_N8_nu2_split4": (S.get_server_heat_specs(8, 5, 2, nu=2), {"split_stage": 4}),
+        "sh_N4_d3_dyn": (S.get_server_heat_specs(4, 4, 3, p_ref=[0.2, 0.3, 0.5]), {}),   # run-time-dimension kernels
+        "sh_N5_d3_static_split2": (S.get_server_heat_specs(5, 3, 3, nu=2, p_ref=[0.2, 0.3, 0.5]), {"split_stage": 2}),
+        "rand_N5_nx12_nu4": (S.get_random_linear_specs(5, 12, 4), {"split_stage": 2}),
+    }
+
+
+@pytest.fixture(scope="module")
+def models(S, O):
+    out = {}
+    for name, (specs, kw) in _configs(S).items():
+        flat = S.flatten_problem(*specs)
+        out[name] = (S.build_model(*specs, **kw), O.Oracle(flat, O.CP), flat)
+    yield out
+    for m, _, _ in out.values():
+        m.close()
+
+
+NAMES = ["car_N3", "sh_N7_full", "sh_N7_split3", "sh_N8_nu2_split4", "sh_N4_d3_dyn", "sh_N5_d3_static_split2", "rand_N5_nx12_nu4"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_operators_match_oracle(models, name):
+    m, o, flat = models[name]
+    rng = np.random.default_rng(hash(name) % 2**32)
+    for trial in range(3):
+        scale = [1.0, 0.05, 5.0][trial]      # small / large arguments reach every branch of the cone projections
+        z = rng.standard_normal(flat.nz) * scale
+        v = rng.standard_normal(flat.nv) * scale
+        x0 = rng.standard_normal(flat.nx) * 0.1
+        assert relerr(m.L(z), o.L(z)) <= OP_TOL
+        assert relerr(m.L_transpose(v), o.Lt(v)) <= OP_TOL
+        assert relerr(m.prox_f(z, 0.1, x0), o.prox_f(z, 0.1, x0)) <= OP_TOL
+        assert relerr(m.prox_h_conj(v, 0.3), o.prox_h_conj(v, 0.3)) <= OP_TOL
+        zo, vo = m.T(z, v, 0.31, 0.29, x0)
+        zr, vr = o.T(z, v, 0.31, 0.29, x0)
+        assert relerr(zo, zr) <= OP_TOL and relerr(vo, vr) <= OP_TOL
+        d_gpu = m.spock_dot(z, v, 0.5 * z, -v, 0.3, 0.2)
+        d_ref = o.dot(z, v, 0.5 * z, -v, 0.3, 0.2)
+        assert abs(d_gpu - d_ref) <= 1e-11 * max(1.0, abs(d_ref))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_adjoint_and_projection_properties(models, name):
+    m, o, flat = models[name]
+    rng = np.random.default_rng(7)
+    z = rng.standard_normal(flat.nz); v = rng.standard_normal(flat.nv); x0 = rng.standard_normal(flat.nx) * 0.1
+    # <L z, v> = <z, L'v>
+    assert abs(np.dot(m.L(z), v) - np.dot(z, m.L_transpose(v))) <= 1e-10 * (1 + abs(np.dot(z, m.L_transpose(v))))
+    # prox_f is (a shift followed by) a projection: applying S1 x S2 twice changes nothing
+    p1 = m.prox_f(z, 0.0, x0)
+    p2 = m.prox_f(p1, 0.0, x0)
+    assert relerr(p2, p1) <= 1e-11
+    # Moreau: v = prox_h*(v) + sigma * Proj_S3(shifted v / sigma); prox_h* of its own output scaled is consistent:
+    # firm non-expansiveness (the reference's own property tests, test/model_algorithms/prox.jl:53-81)
+    for _ in range(5):
+        a = rng.random(flat.nz); b = rng.random(flat.nz)
+        pa = m.prox_f(a, 0.1, x0); pb = m.prox_f(b, 0.1, x0)
+        lhs = np.dot(pa - pb, a - b); rhs = np.dot(pa - pb, pa - pb)
+        assert lhs >= rhs or np.isclose(lhs, rhs)
+        a = rng.random(flat.nv); b = rng.random(flat.nv)
+        pa = m.prox_h_conj(a, 0.1); pb = m.prox_h_conj(b, 0.1)
+        assert np.dot(pa - pb, a - b) >= np.dot(pa - pb, pa - pb) - 1e-12
+
+
+@pytest.mark.parametrize("name,tol,verbose", [("car_N3", 1e-3, "SILENT"), ("sh_N7_split3", 1e-3, "SILENT"),
+                                               ("sh_N7_full", 1e-4, "LOG"), ("sh_N5_d3_static_split2", 1e-3, "SILENT"),
+                                               ("rand_N5_nx12_nu4", 1e-3, "SILENT")])
+def test_cp_solve_matches_oracle(S, O, models, name, tol, verbose):
+    m, o, flat = models[name]
+    m.reset()
+    o.z[:] = 0; o.v[:] = 0
+    x0 = np.full(flat.nx, 0.1)
+    vb = S.LOG if verbose == "LOG" else S.SILENT
+    r = S.solve_model(m, x0, tol=tol, verbose=vb)
+    ro = o.solve(x0, tol=tol, verbose=int(vb), history=6000)
+    assert r["status"] == ro["status"]
+    assert r["iterations"] == ro["iterations"] and r["iter_ref"] == ro["iter_ref"]
+    assert relerr(m.solver_state.z, o.z) <= 1e-8 and relerr(m.solver_state.v, o.v) <= 1e-8
+    h = m.history()
+    assert np.max(np.abs(h["xi1"] - ro["hist_xi1"]) / ro["hist_xi1"]) <= 1e-8
+    assert np.max(np.abs(h["xi2"] - ro["hist_xi2"]) / ro["hist_xi2"]) <= 1e-8
+    # warm start: the state left in the model is the starting point of the next solve (mpc_simulation.jl:40-48)
+    x1 = np.full(flat.nx, 0.11)
+    r2 = S.solve_model(m, x1, tol=tol, verbose=vb)
+    ro2 = o.solve(x1, tol=tol, verbose=int(vb))
+    assert r2["iterations"] == ro2["iterations"]
+    assert relerr(m.solver_state.z, o.z) <= 1e-8
+
+
+def test_known_answer_trace_cp(S, kat_cp):
+    """examples/server_heat/residuals.jl on the GPU: N=7, d=2, nx=nu=5, TOL=1e-5, LOG -> residuals.tikz:29-3187."""
+    specs = S.get_server_heat_specs(7, 5, 2)
+    for kw in ({}, {"split_stage": 3}):
+        m = S.build_model(*specs, **kw)
+        r = S.solve_model(m, np.full(5, 0.1), tol=1e-5, verbose=S.LOG)
+        h = m.history()["xi"]
+        assert r["iterations"] == 3159 and len(h) == 3159
+        assert np.max(np.abs(h - kat_cp) / kat_cp) <= 1e-9
+        m.close()
+
+
+def test_reference_solution_properties(S, models):
+    """test/model_dynamics/implicit_L.jl:59-77 on the GPU iterate of the reference's own fixture."""
+    m, o, flat = models["car_N3"]
+    m.reset()
+    specs = S.get_car_fixture()
+    S.solve_model(m, [0.1, 0.1])
+    z = m.solver_state.z
+    x = z[0:14]; u = z[14:17]; s = z[17:24]; tau = z[24:30]; y = z[30:45]
+    A, B = specs[2].A, specs[2].B
+    for i, (p, w) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1)]):
+        j = i + 1
+        assert np.allclose(x[2 * j:2 * j + 2], A[w] @ x[2 * p:2 * p + 2] + B[w][:, 0] * u[p])
+    E = specs[3][0].E
+    for i in range(3):
+        ch = [2 * i + 1, 2 * i + 2]
+        assert np.allclose(E.T @ y[5 * i:5 * i + 5], tau[[c - 1 for c in ch]] + s[ch])
+
+
+def test_determinism_and_batch(S, O):
+    specs = S.get_server_heat_specs(8, 5, 2)
+    flat = S.flatten_problem(*specs)
+    x0 = np.array([[0.1] * 5, [0.2] * 5, [-0.1, 0.1, 0.05, 0.0, 0.3], [0.0] * 5])
+    m = S.build_model(*specs, batch=4, split_stage=4)
+    rs = S.solve_model(m, x0, tol=1e-3)
+    z_first = m.solver_state.z.copy()
+    m.reset()
+    rs2 = S.solve_model(m, x0, tol=1e-3)
+    assert np.array_equal(z_first, m.solver_state.z)            # bitwise repeatable (gathers, no atomics on data)
+    assert [r["iterations"] for r in rs] == [r["iterations"] for r in rs2]
+    for b in range(4):
+        o = O.Oracle(flat, O.CP)
+        ro = o.solve(x0[b], tol=1e-3)
+        assert rs[b]["iterations"] == ro["iterations"]
+        assert relerr(z_first[b], o.z) <= 1e-8
+    m.close()
+
+
+def test_full_size_cfg2_properties(S):
+    """BASELINE.json config 2 (4096 leaves, reference N=13, nx=5): nu=5 (reference-faithful) and nu=2.
+    Size-independent checks: adjointness, S1/S2 idempotence, dynamics feasibility of the iterate."""
+    rng = np.random.default_rng(3)
+    for nu in (5, 2):
+        specs = S.get_server_heat_specs(13, 5, 2, nu=nu)
+        flat = S.flatten_problem(*specs)
+        m = S.build_model(*specs, max_iter=200)
+        z = rng.standard_normal(flat.nz); v = rng.standard_normal(flat.nv); x0 = np.full(5, 0.1)
+        lhs = np.dot(m.L(z), v); rhs = np.dot(z, m.L_transpose(v))
+        assert abs(lhs - rhs) <= 1e-9 * (1 + abs(rhs))
+        p1 = m.prox_f(z, 0.0, x0); p2 = m.prox_f(p1, 0.0, x0)
+        assert relerr(p2, p1) <= 1e-10
+        r = S.solve_model(m, x0, tol=1e-3)
+        zz = m.solver_state.z
+        sl = flat.z_slices()
+        x = zz[sl["x"]].reshape(flat.n, 5); u = zz[sl["u"]].reshape(flat.nn, nu)
+        A, B = specs[2].A, specs[2].B
+        j = np.arange(1, flat.n); par = (j - 1) // 2; w = (j + 1) % 2
+        pred = np.where((w == 0)[:, None], x[par] @ A[0].T + u[par] @ B[0].T, x[par] @ A[1].T + u[par] @ B[1].T)
+        assert np.max(np.abs(x[1:] - pred)) <= 1e-9 * max(1.0, np.max(np.abs(x)))
+        assert np.allclose(x[0], x0)
+        assert r["iterations"] >= 1
+        m.close()
