@@ -1,0 +1,144 @@
+"""Host logic: the driver (spock_abi.cpp) and the kernel bodies (spock_device.hpp / spock_group.hpp), compiled
+for the host by tests/emu (emulation harness = test infrastructure, never loaded by the product), against the
+oracle.  This is what lets the launch geometry, the ownership maps, the ping-pong parity and the on-device
+termination logic be debugged without a GPU; the real parity tests are tests/test_gpu_parity.py."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "libspock_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")], stdout=subprocess.DEVNULL)
+    return EMU
+
+
+CASES = {
+    "car": (lambda S: S.get_car_fixture(), {}),
+    "sh7": (lambda S: S.get_server_heat_specs(7, 5, 2), {}),
+    "sh7_split3": (lambda S: S.get_server_heat_specs(7, 5, 2), {"split_stage": 3}),
+    "sh6_nu2_split2": (lambda S: S.get_server_heat_specs(6, 5, 2, nu=2), {"split_stage": 2}),
+    "d3_dyn": (lambda S: S.get_server_heat_specs(4, 4, 3, p_ref=[0.2, 0.3, 0.5]), {"split_stage": 1}),
+    "d3_static": (lambda S: S.get_server_heat_specs(4, 3, 3, nu=2, p_ref=[0.2, 0.3, 0.5]), {"split_stage": 2}),
+    "rand_nx12": (lambda S: S.get_random_linear_specs(5, 12, 4), {"split_stage": 2}),
+    "tv_risk": (None, {}),
+}
+
+
+def _specs(S, name):
+    if name == "tv_risk":        # total-variation risk measure: ny = 3d, a single Nonnegatives cone (risk_measures.jl:138-147)
+        tree, cost, dyn, _, con = S.get_server_heat_specs(4, 3, 2)
+        return tree, cost, dyn, S.get_uniform_rms_tv_v2([0.4, 0.6], 0.2, 2, 4), con
+    return CASES[name][0](S)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_emulated_operators(S, O, emu, name):
+    specs = _specs(S, name)
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, lib_path=emu, **CASES[name][1])
+    o = O.Oracle(flat, O.CP)
+    rng = np.random.default_rng(5)
+    for scale in (1.0, 0.05, 5.0):
+        z = rng.standard_normal(flat.nz) * scale; v = rng.standard_normal(flat.nv) * scale
+        x0 = rng.standard_normal(flat.nx) * 0.1
+        assert relerr(m.L(z), o.L(z)) <= 1e-13
+        assert relerr(m.L_transpose(v), o.Lt(v)) <= 1e-13
+        assert relerr(m.prox_f(z, 0.1, x0), o.prox_f(z, 0.1, x0)) <= 1e-12
+        assert relerr(m.prox_h_conj(v, 0.3), o.prox_h_conj(v, 0.3)) <= 1e-13
+        zo, vo = m.T(z, v, 0.3, 0.25, x0); zr, vr = o.T(z, v, 0.3, 0.25, x0)
+        assert relerr(zo, zr) <= 1e-12 and relerr(vo, vr) <= 1e-12
+        assert abs(m.spock_dot(z, v, v[:flat.nz] if flat.nv >= flat.nz else z, v, 0.3, 0.2)
+                   - o.dot(z, v, v[:flat.nz] if flat.nv >= flat.nz else z, v, 0.3, 0.2)) <= 1e-10 * (1 + abs(np.dot(z, z)))
+    m.close()
+
+
+@pytest.mark.parametrize("name,tol,log", [("car", 1e-3, False), ("sh7_split3", 1e-3, False), ("sh7", 1e-4, True),
+                                          ("d3_static", 1e-3, False), ("tv_risk", 1e-3, False)])
+def test_emulated_cp_driver(S, O, emu, name, tol, log):
+    specs = _specs(S, name)
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, lib_path=emu, graph_iters=-6, **CASES[name][1])
+    o = O.Oracle(flat, O.CP)
+    x0 = np.full(flat.nx, 0.1)
+    vb = S.LOG if log else S.SILENT
+    r = S.solve_model(m, x0, tol=tol, verbose=vb)
+    ro = o.solve(x0, tol=tol, verbose=int(vb), history=6000)
+    assert (r["iterations"], r["iter_ref"], r["status"]) == (ro["iterations"], ro["iter_ref"], ro["status"])
+    assert relerr(m.solver_state.z, o.z) <= 1e-9 and relerr(m.solver_state.v, o.v) <= 1e-9
+    h = m.history()
+    assert len(h["xi1"]) == ro["iterations"]
+    assert np.max(np.abs(h["xi1"] - ro["hist_xi1"]) / ro["hist_xi1"]) <= 1e-8
+    if log:
+        assert np.max(np.abs(h["xi"] - ro["hist_xi"]) / ro["hist_xi"]) <= 1e-8
+    # warm start + explicit z0/v0 + explicit step sizes (cpock.jl:174-183, cp.jl:198-201)
+    r2 = S.solve_model(m, x0 * 1.1, tol=tol, verbose=vb); ro2 = o.solve(x0 * 1.1, tol=tol, verbose=int(vb))
+    assert r2["iterations"] == ro2["iterations"] and relerr(m.solver_state.z, o.z) <= 1e-9
+    z0 = np.zeros(flat.nz); v0 = np.zeros(flat.nv)
+    r3 = S.solve_model(m, x0, tol=tol, verbose=vb, z0=z0, v0=v0, gamma=0.25, sigma=0.3)
+    ro3 = o.solve(x0, tol=tol, verbose=int(vb), z0=z0, v0=v0, gamma=0.25, sigma=0.3)
+    assert r3["iterations"] == ro3["iterations"] and relerr(m.solver_state.z, o.z) <= 1e-9
+    with pytest.raises(ValueError):
+        S.solve_model(m, x0, z0=z0)
+    m.close()
+
+
+def test_emulated_known_answer_trace(S, emu, kat_cp):
+    m = S.build_model(*S.get_server_heat_specs(7, 5, 2), lib_path=emu, split_stage=3)
+    r = S.solve_model(m, np.full(5, 0.1), tol=1e-5, verbose=S.LOG)
+    h = m.history()["xi"]
+    assert r["iterations"] == 3159 and np.max(np.abs(h - kat_cp) / kat_cp) <= 1e-9
+    m.close()
+
+
+def test_emulated_batch_and_max_iter(S, O, emu):
+    specs = S.get_server_heat_specs(5, 5, 2)
+    flat = S.flatten_problem(*specs)
+    x0 = np.array([[0.1] * 5, [0.2] * 5, [-0.1, 0.1, 0.05, 0.0, 0.3]])
+    m = S.build_model(*specs, lib_path=emu, batch=3, split_stage=2, max_iter=1050)
+    rs = S.solve_model(m, x0, tol=1e-3)
+    for b in range(3):
+        o = O.Oracle(flat, O.CP)
+        ro = o.solve(x0[b], tol=1e-3, max_iter=1050)
+        assert (rs[b]["iterations"], rs[b]["status"]) == (ro["iterations"], ro["status"])
+        assert relerr(m.solver_state.z[b], o.z) <= 1e-9
+    assert sorted(r["status"] for r in rs) == [0, 0, 1]      # instance 1 needs 1117 iterations > 1050
+    m.close()
+
+
+def test_emulated_build_products_match_oracle(S, O, emu):
+    """The product's host build step (spock_host.cpp: eigen-decomposition based projector, explicit Rtilde
+    inverse) against the oracle's (MGS projector, Cholesky solves): two independent routes to the same numbers."""
+    for specs in (S.get_car_fixture(), S.get_server_heat_specs(5, 5, 2, nu=2), S.get_random_linear_specs(4, 6, 3)):
+        flat = S.flatten_problem(*specs)
+        m = S.build_model(*specs, lib_path=emu)
+        bp = O.Oracle(flat, O.CP).build_products()
+        assert relerr(m.build_product(0), bp["P"]) <= 1e-12
+        assert relerr(m.build_product(1), bp["K"]) <= 1e-12
+        assert relerr(m.build_product(3), bp["ABK"]) <= 1e-12
+        assert relerr(m.build_product(4), bp["ls"]) <= 1e-13
+        assert relerr(m.build_product(5), bp["sqrtQ"]) <= 1e-14
+        nu, N = flat.nu, flat.N
+        Rinv = m.build_product(2).reshape(N - 1, nu, nu)
+        Lc = bp["Rchol"].reshape(N - 1, nu, nu).transpose(0, 2, 1)      # column-major lower factors
+        for t in range(N - 1):
+            assert np.allclose(Rinv[t] @ (Lc[t] @ Lc[t].T), np.eye(nu), atol=1e-12)
+        m.close()
+
+
+def test_unsupported_inputs(S, emu):
+    tree, cost, dyn, rms, con = S.get_server_heat_specs(4, 3, 2)
+    with pytest.raises(S.SpockError) as e:
+        S.build_model(tree, cost, dyn, rms, con, S.SolverOptions(S.SP, None), lib_path=emu)
+    assert e.value.code == 2
+    bad = S.generate_scenario_tree_uniform_branching_factor_v2(4, 2, 3, 3)
+    bad.anc = bad.anc.copy(); bad.anc[5] = 1
+    with pytest.raises(S.SpockError):
+        S.build_model(bad, cost, dyn, rms, con, lib_path=emu)
