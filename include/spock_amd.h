@@ -157,9 +157,15 @@ int spock_op_T(spock_handle_t h, const double *x0, const double *z, const double
  * 3 ABK, 4 kernel projector, 5 sqrtQ, 6 sqrtR, 7 sqrtQN.  *len receives the element count. */
 int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_t cap, int32_t *len);
 
-/* device-side timing of the last solve: number of kernel launches per kind and their summed HIP-event
- * time; kinds: 0 whole solve.  ms_out/launches_out: [n_kinds]. */
+/* device time of the last solve divided by its iteration count, and that count */
 int spock_get_timing(spock_handle_t h, double *iter_ms_avg, int32_t *iters_timed);
+/* measurement aid (no reference counterpart): runs `reps` further CP iterations on the current state with a
+ * HIP event before and after every kernel launch on the handle's stream.  avg_ms / launches: [4], average
+ * duration and launch count per kernel kind: 0 subtree phase A, 1 crown, 2 subtree phase B, 3 whole-tree kernel. */
+int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_t *launches);
+/* measurement aid: clock stamps (shader clock, 100 MHz wall clock) written by workgroup 0 of instance 0 during the
+ * last spock_profile_kernels run with SPOCK_AMD_DEBUG_FLAGS including 512; out: [3 kernels][64 stamps][2]. */
+int spock_debug_stamps(spock_handle_t h, uint64_t *out);
 
 const char *spock_last_error(void);
 int spock_version(void);

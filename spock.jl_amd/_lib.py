@@ -66,6 +66,8 @@ SYMBOLS = {
     "spock_op_T": (C.c_int, [_P, _P, _P, _P, _D, _D, _P, _P]),
     "spock_get_build_product": (C.c_int, [_P, _I, _P, _I, C.POINTER(_I)]),
     "spock_get_timing": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_I)]),
+    "spock_profile_kernels": (C.c_int, [_P, _I, _P, _P]),
+    "spock_debug_stamps": (C.c_int, [_P, _P]),
     "spock_last_error": (C.c_char_p, []),
     "spock_version": (C.c_int, []),
 }

@@ -31,12 +31,13 @@ struct spock_handle_s {
     void *stream = nullptr, *ev0 = nullptr, *ev1 = nullptr, *graph = nullptr;
     // device memory
     double *d_mats = nullptr, *d_z[2] = {nullptr, nullptr}, *d_v[2] = {nullptr, nullptr};
-    double *d_dbuf = nullptr, *d_qroot = nullptr, *d_partials = nullptr, *d_x0 = nullptr, *d_hist = nullptr;
+    double *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_partials = nullptr, *d_x0 = nullptr, *d_hist = nullptr;
     Ctl *d_ctl = nullptr;
+    unsigned long long *d_dbg = nullptr;
     int hist_cap = 0;
     // single-instance buffers of the operator-level entry points
     double *o_z[2] = {nullptr, nullptr}, *o_v[2] = {nullptr, nullptr}, *o_dbuf = nullptr, *o_qroot = nullptr,
-           *o_partials = nullptr, *o_x0 = nullptr;
+           *o_cbuf = nullptr, *o_partials = nullptr, *o_x0 = nullptr;
     Ctl *o_ctl = nullptr;
     std::vector<Ctl> h_ctl;
     double last_ms = 0.;
@@ -70,11 +71,11 @@ KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
     if (!op) {
         a.z_in = h->d_z[parity]; a.v_in = h->d_v[parity];
         a.z_out = h->d_z[1 - parity]; a.v_out = h->d_v[1 - parity];
-        a.dbuf = h->d_dbuf; a.qroot = h->d_qroot; a.partials = h->d_partials; a.ctl = h->d_ctl; a.x0 = h->d_x0;
-        a.hist = h->d_hist; a.hist_cap = h->hist_cap; a.batch = h->batch;
+        a.dbuf = h->d_dbuf; a.qroot = h->d_qroot; a.cbuf = h->d_cbuf; a.partials = h->d_partials; a.ctl = h->d_ctl; a.x0 = h->d_x0;
+        a.hist = h->d_hist; a.hist_cap = h->hist_cap; a.batch = h->batch; a.dbg = h->d_dbg;
     } else {
         a.z_in = h->o_z[0]; a.v_in = h->o_v[0]; a.z_out = h->o_z[1]; a.v_out = h->o_v[1];
-        a.dbuf = h->o_dbuf; a.qroot = h->o_qroot; a.partials = h->o_partials; a.ctl = h->o_ctl; a.x0 = h->o_x0;
+        a.dbuf = h->o_dbuf; a.qroot = h->o_qroot; a.cbuf = h->o_cbuf; a.partials = h->o_partials; a.ctl = h->o_ctl; a.x0 = h->o_x0;
         a.hist = nullptr; a.hist_cap = 0; a.batch = 1;
     }
     a.parity = parity;
@@ -100,6 +101,7 @@ int ensure_op_buffers(spock_handle_s *h) {
     for (int k = 0; k < 2 && !e; ++k) { e = dev_alloc(h, &h->o_z[k], (size_t)dm.nz); if (!e) e = dev_alloc(h, &h->o_v[k], (size_t)dm.nv); }
     if (!e) e = dev_alloc(h, &h->o_dbuf, (size_t)dm.nn * dm.nu);
     if (!e) e = dev_alloc(h, &h->o_qroot, (size_t)dm.nsub * dm.nx);
+    if (!e) e = dev_alloc(h, &h->o_cbuf, (size_t)(group_threads(dm.d, dm.t0 + 1) + 1) * (dm.nx + dm.nu));
     if (!e) e = dev_alloc(h, &h->o_partials, (size_t)(dm.nsub + 1) * kPartialStride);
     if (!e) e = dev_alloc(h, &h->o_x0, (size_t)dm.nx);
     if (!e) e = dev_alloc(h, &h->o_ctl, 1);
@@ -224,8 +226,10 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     }
     h->hist_cap = h->max_iter + 2;
     if ((e = dev_alloc(h, &h->d_dbuf, B * dm.nn * dm.nu)) || (e = dev_alloc(h, &h->d_qroot, B * dm.nsub * dm.nx)) ||
+        (e = dev_alloc(h, &h->d_cbuf, B * (size_t)(group_threads(dm.d, dm.t0 + 1) + 1) * (dm.nx + dm.nu))) ||
         (e = dev_alloc(h, &h->d_partials, B * (dm.nsub + 1) * kPartialStride)) || (e = dev_alloc(h, &h->d_x0, B * dm.nx)) ||
-        (e = dev_alloc(h, &h->d_hist, B * (size_t)h->hist_cap * kHistStride)) || (e = dev_alloc(h, &h->d_ctl, B)))
+        (e = dev_alloc(h, &h->d_hist, B * (size_t)h->hist_cap * kHistStride)) || (e = dev_alloc(h, &h->d_ctl, B)) ||
+        (e = dev_alloc(h, &h->d_dbg, (size_t)3 * 64 * 2)))
         return bail(e, "hipMalloc(workspace)");
     h->h_ctl.assign(B, fresh_ctl(h, 0., 0., 0., SPOCK_SILENT));
     for (auto &c : h->h_ctl) c.done = 1;
@@ -432,6 +436,64 @@ int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_
     }
     if (len) *len = (int32_t)src->size();
     if (out) { const size_t k = src->size() < (size_t)cap ? src->size() : (size_t)cap; std::memcpy(out, src->data(), k * sizeof(double)); }
+    return SPOCK_OK;
+}
+
+int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_t *launches) {
+    if (!h || !avg_ms || reps < 1) return fail(SPOCK_ERR_BAD_ARG, "bad argument");
+    // `reps` further CP iterations on the current state, launched one kernel at a time with a HIP event before
+    // and after each launch on the handle's stream; per kind: 0 SUB_A, 1 CROWN, 2 SUB_B, 3 FULL.
+    const size_t B = (size_t)h->batch;
+    const double g = 0.99 / std::sqrt(h->L_norm);
+    Ctl c = fresh_ctl(h, g, g, 0., SPOCK_SILENT);
+    c.max_iter = 1 << 30;
+    std::vector<Ctl> cs(B, c);
+    RTCHECK(rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream));
+    const bool split = h->bp.dm.t0 > 0;
+    const int kinds[3] = {MODE_SUB_A, MODE_CROWN, MODE_SUB_B};
+    const int per_it = split ? 3 : 1;
+    std::vector<void *> ev((size_t)reps * per_it * 2, nullptr);
+    for (auto &e : ev) RTCHECK(rt::event_create(&e));
+    size_t k = 0;
+    for (int it = 0; it < reps; ++it) {
+        unsigned dbg = 0;
+        if (const char *e = std::getenv("SPOCK_AMD_DEBUG_FLAGS")) dbg = (unsigned)std::atoi(e);
+        const KArgs a = make_args(h, false, it & 1, dbg);
+        for (int j = 0; j < per_it; ++j) {
+            RTCHECK(rt::event_record(ev[k++], h->stream));
+            RTCHECK(launch_group(split ? kinds[j] : MODE_FULL, a, h->stream));
+            RTCHECK(rt::event_record(ev[k++], h->stream));
+        }
+    }
+    RTCHECK(rt::sync(h->stream));
+    double sum[4] = {0., 0., 0., 0.};
+    int cnt[4] = {0, 0, 0, 0};
+    k = 0;
+    for (int it = 0; it < reps; ++it)
+        for (int j = 0; j < per_it; ++j) {
+            float ms = 0.f;
+            RTCHECK(rt::event_elapsed(&ms, ev[k], ev[k + 1]));
+            k += 2;
+            const int kind = split ? j : 3;
+            sum[kind] += ms; cnt[kind] += 1;
+        }
+    for (auto e : ev) rt::event_destroy(e);
+    for (int q = 0; q < 4; ++q) { avg_ms[q] = cnt[q] ? sum[q] / cnt[q] : 0.; if (launches) launches[q] = cnt[q]; }
+    // leave a consistent state behind: an odd number of iterations ends in buffer 1
+    if (reps & 1) {
+        RTCHECK(rt::d2d(h->d_z[0], h->d_z[1], B * h->bp.dm.nz * sizeof(double), h->stream));
+        RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * h->bp.dm.nv * sizeof(double), h->stream));
+    }
+    for (auto &x : cs) x.done = 1;
+    RTCHECK(rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream));
+    RTCHECK(rt::sync(h->stream));
+    return SPOCK_OK;
+}
+
+int spock_debug_stamps(spock_handle_t h, uint64_t *out /* [3][64][2] */) {
+    if (!h || !out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    RTCHECK(rt::d2h(out, h->d_dbg, sizeof(uint64_t) * 3 * 64 * 2, h->stream));
+    RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
 }
 

@@ -31,18 +31,38 @@
 
 namespace spock {
 
-template <int NX, int NU, int D, int NY>
+// The matrix pool is read-only for the lifetime of a handle.  Addressing it through the CONSTANT address
+// space lets the compiler fetch every wave-uniform matrix element with scalar loads (s_load_dwordx16 into
+// SGPRs that feed v_fma_f64 directly) instead of 64 identical per-lane vector loads; per-lane (divergent)
+// indices still work and fall back to vector loads.
+#ifdef SPOCK_HOST_EMU
+typedef const double *MatPtr;
+#else
+typedef const __attribute__((address_space(4))) double *MatPtr;
+#endif
+
+// cost-matrix mode (template parameter CM of the dimension policies)
+constexpr int CM_GENERAL = 0;      // per-node sqrtQ / sqrtR / sqrtQN (indexed by node: divergent loads)
+constexpr int CM_SHARED = 1;       // one matrix of each kind shared by every node (uniform: scalar loads)
+constexpr int CM_SHARED_DIAG = 2;  // shared and diagonal: the mat-vecs are element-wise products
+
+// For finite data the element-wise (diagonal) product is bit-identical to the dense one: the skipped terms
+// are exact zeros.
+template <int NX, int NU, int D, int NY, int CM>
 struct StaticDims {
     static constexpr int MAXNX = NX, MAXNU = NU, MAXD = D, MAXNY = NY, MAXM = NY + 2 * D, UNR = 128;
+    static constexpr bool DIAG = (CM == CM_SHARED_DIAG), SHARED = (CM != CM_GENERAL);
     SPK_DEV explicit StaticDims(const Dims &) {}
     SPK_DEV constexpr int nx() const { return NX; }
     SPK_DEV constexpr int nu() const { return NU; }
     SPK_DEV constexpr int d() const { return D; }
     SPK_DEV constexpr int ny() const { return NY; }
 };
+template <int CM>
 struct DynDims {
     static constexpr int MAXNX = kDynMaxNx, MAXNU = kDynMaxNu, MAXD = kDynMaxD, MAXNY = kDynMaxNy,
                          MAXM = kDynMaxNy + 2 * kDynMaxD, UNR = 1;
+    static constexpr bool DIAG = (CM == CM_SHARED_DIAG), SHARED = (CM != CM_GENERAL);
     int nx_, nu_, d_, ny_;
     SPK_DEV explicit DynDims(const Dims &dm) : nx_(dm.nx), nu_(dm.nu), d_(dm.d), ny_(dm.ny) {}
     SPK_DEV int nx() const { return nx_; }
@@ -55,11 +75,12 @@ struct DynDims {
 template <class P>
 struct TState {
     int lvl, pos, node, c0;   // level and position inside the group, global node, first child
+    int stage;                // global stage of the node
     bool active;
     bool kids_leaf;           // children are leaves of the TREE (this thread also owns them)
     bool kids_gleaf;          // children are leaves of the GROUP (crown: the subtree roots)
-    double xb[P::MAXNX];      // xbar_i (phase A)  -> x_i (after the forward sweep)
-    double ub[P::MAXNU];      // ubar_i            -> u_i
+    double xb[P::MAXNX];      // phase A: c_i = U ubar_i - xbar_i  -> x_i (after the forward sweep)
+    double ub[P::MAXNU];      // phase A: e_i = Rt^-1 ubar_i       -> u_i
     double dd[P::MAXNU];      // d_i of the Riccati recursion
     double xl[P::MAXD][P::MAXNX];  // leaf children: xbar_j -> x_j
 };
@@ -69,6 +90,20 @@ SPK_DEV double spk_clamp(double x, double lo, double hi) { return x > hi ? hi : 
 
 // event of child slot c: w = (j % d) + 1 with j = 2 + (i-1) d + c, 1-based (scenario_tree.jl:77)
 SPK_DEV int slot_event(int c, int d) { return (2 + c) % d; }
+
+// y (+)= S x for a symmetric cost square root S (n x n)
+template <class P, bool ACC>
+SPK_DEV void sym_mv(int n, MatPtr S, const double *x, double *y) {
+    SPK_UNROLL for (int r = 0; r < n; ++r) {
+        double t;
+        if (P::DIAG) t = S[r + r * n] * x[r];
+        else {
+            t = 0.;
+            SPK_UNROLL for (int k = 0; k < n; ++k) t += S[r + k * n] * x[k];
+        }
+        if (ACC) y[r] += t; else y[r] = t;
+    }
+}
 
 // (t; x) second-order-cone projection, MOI ordering t first (risk_measures.jl:47-71)
 template <int MAXLEN>
@@ -80,9 +115,10 @@ SPK_DEV void project_soc(double *vec, int len) {
     } else if (x_norm <= -t) {
         for (int k = 0; k < len; ++k) vec[k] = 0.;
     } else {
-        double t2 = (t + x_norm) / 2.;
+        const double t2 = (t + x_norm) / 2.;
+        const double sc = t2 / x_norm;   // the reference evaluates (t2 * vec[k]) / x_norm: same up to one rounding
         vec[0] = t2;
-        for (int k = 1; k < len; ++k) vec[k] = t2 * vec[k] / x_norm;
+        for (int k = 1; k < len; ++k) vec[k] = sc * vec[k];
     }
 }
 
@@ -102,35 +138,32 @@ SPK_DEV void init_geometry(const P &p, const Dims &dm, int tau, int root_stage, 
     for (int k = 0; k < s.lvl; ++k) span *= d;
     s.node = dm.first[root_stage + s.lvl] + root_pos * span + s.pos;
     s.c0 = s.node * d + 1;
+    s.stage = root_stage + s.lvl;
     s.kids_gleaf = s.active && (s.lvl == stages - 2);
     s.kids_leaf = s.kids_gleaf && !crown && (root_stage + stages == dm.N);
     if (crown) s.kids_leaf = false;
 }
 
 // ------------------------------------------------------------------------------------------------
-// phase A, node-local:  zbar0 = (-gamma) L'v + z on the entries owned by node i, then S2.
+// phase A, node-local:  zbar0 = (-gamma) L'v + z on the entries owned by node i, then S2, then the
+// node-local terms of the S1 recursion: c_i = U_t ubar_i - xbar_i and e_i = Rt^-1 ubar_i (spock_host.cpp).
 template <class P>
-SPK_DEV void a_local(const P &p, const Dims &dm, const double *M, const double *z, const double *v, double *zo,
-                     TState<P> &s, double gamma, unsigned flags) {
+SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
+                     const double *__restrict__ v, double *__restrict__ zo, TState<P> &s, double gamma, unsigned flags) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu;
     const double mg = -gamma;
     const bool raw = (flags & F_RAW_LT) != 0;
+    double xbar[P::MAXNX], ubar[P::MAXNU];
     // x_i <- Gamma' v7 + sum_j sqrtQ_j v3_j  (implicit_l.jl:351-373)
     {
         double acc[P::MAXNX];
         SPK_UNROLL for (int k = 0; k < nx; ++k) acc[k] = v[dm.o7 + i * nxu + k];
         SPK_UNROLL for (int c = 0; c < d; ++c) {
             const int jn = s.c0 + c - 1;
-            const double *SQ = M + dm.mSqQ + (dm.nQ == 1 ? 0 : jn) * nx * nx;
-            const double *v3 = v + dm.o3 + jn * nx;
-            SPK_UNROLL for (int r = 0; r < nx; ++r) {
-                double t = 0.;
-                SPK_UNROLL for (int k = 0; k < nx; ++k) t += SQ[r + k * nx] * v3[k];
-                acc[r] += t;
-            }
+            sym_mv<P, true>(nx, M + dm.mSqQ + (P::SHARED ? 0 : jn) * nx * nx, v + dm.o3 + jn * nx, acc);
         }
-        SPK_UNROLL for (int k = 0; k < nx; ++k) s.xb[k] = mg * acc[k] + z[dm.zx + i * nx + k];
+        SPK_UNROLL for (int k = 0; k < nx; ++k) xbar[k] = mg * acc[k] + z[dm.zx + i * nx + k];
     }
     // u_i <- Gamma' v7 + sum_j sqrtR_j v4_j  (implicit_l.jl:399-420)
     {
@@ -138,20 +171,14 @@ SPK_DEV void a_local(const P &p, const Dims &dm, const double *M, const double *
         SPK_UNROLL for (int k = 0; k < nu; ++k) acc[k] = v[dm.o7 + i * nxu + nx + k];
         SPK_UNROLL for (int c = 0; c < d; ++c) {
             const int jn = s.c0 + c - 1;
-            const double *SR = M + dm.mSqR + (dm.nR == 1 ? 0 : jn) * nu * nu;
-            const double *v4 = v + dm.o4 + jn * nu;
-            SPK_UNROLL for (int r = 0; r < nu; ++r) {
-                double t = 0.;
-                SPK_UNROLL for (int k = 0; k < nu; ++k) t += SR[r + k * nu] * v4[k];
-                acc[r] += t;
-            }
+            sym_mv<P, true>(nu, M + dm.mSqR + (P::SHARED ? 0 : jn) * nu * nu, v + dm.o4 + jn * nu, acc);
         }
-        SPK_UNROLL for (int k = 0; k < nu; ++k) s.ub[k] = mg * acc[k] + z[dm.zu + i * nu + k];
+        SPK_UNROLL for (int k = 0; k < nu; ++k) ubar[k] = mg * acc[k] + z[dm.zu + i * nu + k];
     }
     // [y_i ; s_children ; tau_children]  (implicit_l.jl:423-448)
     double vec[P::MAXM];
     const double v2i = v[dm.o2 + i];
-    const double *bb = M + dm.mb;
+    const MatPtr bb = M + dm.mb;
     SPK_UNROLL for (int k = 0; k < ny; ++k) vec[k] = mg * (v[i * ny + k] - bb[k] * v2i) + z[dm.zy + i * ny + k];
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = s.c0 + c;
@@ -165,18 +192,14 @@ SPK_DEV void a_local(const P &p, const Dims &dm, const double *M, const double *
     if (s.kids_leaf) {
         SPK_UNROLL for (int c = 0; c < d; ++c) {
             const int j = s.c0 + c, li = j - dm.nn;
-            const double *SN = M + dm.mSqQN + (dm.nQN == 1 ? 0 : li) * nx * nx;
-            const double *v11 = v + dm.o11 + li * nx;
-            SPK_UNROLL for (int r = 0; r < nx; ++r) {
-                double t = 0.;
-                SPK_UNROLL for (int k = 0; k < nx; ++k) t += SN[r + k * nx] * v11[k];
-                s.xl[c][r] = mg * (v[dm.o14 + li * nx + r] + t) + z[dm.zx + j * nx + r];
-            }
+            double t[P::MAXNX];
+            sym_mv<P, false>(nx, M + dm.mSqQN + (P::SHARED ? 0 : li) * nx * nx, v + dm.o11 + li * nx, t);
+            SPK_UNROLL for (int r = 0; r < nx; ++r) s.xl[c][r] = mg * (v[dm.o14 + li * nx + r] + t[r]) + z[dm.zx + j * nx + r];
         }
     }
     if (raw) {  // operator L': store every owned entry as is
-        SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + i * nx + k] = s.xb[k];
-        SPK_UNROLL for (int k = 0; k < nu; ++k) zo[dm.zu + i * nu + k] = s.ub[k];
+        SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + i * nx + k] = xbar[k];
+        SPK_UNROLL for (int k = 0; k < nu; ++k) zo[dm.zu + i * nu + k] = ubar[k];
         SPK_UNROLL for (int k = 0; k < ny; ++k) zo[dm.zy + i * ny + k] = vec[k];
         SPK_UNROLL for (int c = 0; c < d; ++c) {
             const int j = s.c0 + c;
@@ -191,7 +214,7 @@ SPK_DEV void a_local(const P &p, const Dims &dm, const double *M, const double *
     if (i == 0) zo[dm.zs] = (mg * v[dm.o2] + z[dm.zs]) - gamma;
     // S2: projector onto ker [E' -I -I ; F' 0 0] applied to [y_i; s_ch; tau_ch]  (implicit_l.jl:708-726)
     const int m = ny + 2 * d;
-    const double *LS = M + dm.mLs;
+    const MatPtr LS = M + dm.mLs;
     SPK_UNROLL for (int r = 0; r < m; ++r) {
         double t = 0.;
         SPK_UNROLL for (int k = 0; k < m; ++k) t += LS[r + k * m] * vec[k];
@@ -199,123 +222,117 @@ SPK_DEV void a_local(const P &p, const Dims &dm, const double *M, const double *
         else if (r < ny + d) zo[dm.zs + s.c0 + (r - ny)] = t;
         else zo[dm.zt + s.c0 + (r - ny - d) - 1] = t;
     }
+    // node-local terms of the S1 recursion
+    const MatPtr Ut = M + dm.mU + s.stage * nx * nu;
+    const MatPtr Ri = M + dm.mRinv + s.stage * nu * nu;
+    SPK_UNROLL for (int r = 0; r < nx; ++r) {
+        double t = 0.;
+        SPK_UNROLL for (int k = 0; k < nu; ++k) t += Ut[r + k * nx] * ubar[k];
+        s.xb[r] = t - xbar[r];
+    }
+    SPK_UNROLL for (int r = 0; r < nu; ++r) {
+        double t = 0.;
+        SPK_UNROLL for (int k = 0; k < nu; ++k) t += Ri[r + k * nu] * ubar[k];
+        s.ub[r] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// one level of the backward recursion (implicit_l.jl:584-637) for the thread's node at global stage t.
+// one level of the backward recursion (implicit_l.jl:584-637, restructured: see spock_host.cpp) for the
+// thread's node at global stage t:  q_i = c_i + sum_j W_{t,j} q_j,  d_i = e_i - sum_j V_{t,j} q_j.
 //   ex    : LDS exchange buffer, [group non-leaf local index][nx]
 //   qg    : global q of the group leaves when they are subtree roots (crown), else nullptr
 //   q_out : where the group root's q goes (subtree -> global), or nullptr
 template <class P>
-SPK_DEV void bwd_node(const P &p, const Dims &dm, const double *M, int t, int tau, double *ex, const double *qg,
-                      double *q_out, TState<P> &s) {
+SPK_DEV void bwd_node(const P &p, const Dims &dm, MatPtr M, int t, int tau, double *ex,
+                      const double *qg, double *q_out, TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
-    double qc[P::MAXD][P::MAXNX];
+    double qi[P::MAXNX], di[P::MAXNU];
+    SPK_UNROLL for (int k = 0; k < nx; ++k) qi[k] = s.xb[k];
+    SPK_UNROLL for (int k = 0; k < nu; ++k) di[k] = s.ub[k];
     SPK_UNROLL for (int c = 0; c < d; ++c) {
-        if (s.kids_leaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[c][k] = -s.xl[c][k]; }   // q_leaf = -xbar_leaf (:578-582)
-        else if (s.kids_gleaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[c][k] = qg[(s.pos * d + c) * nx + k]; }
-        else { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[c][k] = ex[(tau * d + 1 + c) * nx + k]; }
-    }
-    // d_i = Rtilde^-1 (ubar_i - sum_j B_w' q_j)   (:586-604)
-    double rhs[P::MAXNU];
-    SPK_UNROLL for (int k = 0; k < nu; ++k) rhs[k] = 0.;
-    SPK_UNROLL for (int c = 0; c < d; ++c) {
-        const double *Bw = M + dm.mB + slot_event(c, d) * nx * nu;
-        SPK_UNROLL for (int col = 0; col < nu; ++col) {
-            double t1 = 0.;
-            SPK_UNROLL for (int r = 0; r < nx; ++r) t1 += Bw[r + col * nx] * qc[c][r];
-            rhs[col] += t1;
-        }
-    }
-    SPK_UNROLL for (int k = 0; k < nu; ++k) rhs[k] = s.ub[k] - rhs[k];
-    const double *Ri = M + dm.mRinv + t * nu * nu;
-    SPK_UNROLL for (int r = 0; r < nu; ++r) {
-        double t1 = 0.;
-        SPK_UNROLL for (int k = 0; k < nu; ++k) t1 += Ri[r + k * nu] * rhs[k];
-        s.dd[r] = t1;
-    }
-    // q_i = sum_j ABK_j' (P_j B_w d_i + q_j) + K_i' (d_i - ubar_i) - xbar_i   (:606-636)
-    double qi[P::MAXNX];
-    SPK_UNROLL for (int k = 0; k < nx; ++k) qi[k] = 0.;
-    const double *Pc = M + dm.mP + (t + 1) * nx * nx;
-    SPK_UNROLL for (int c = 0; c < d; ++c) {
-        const double *Bw = M + dm.mB + slot_event(c, d) * nx * nu;
-        const double *Ab = M + dm.mABK + ((t + 1) * d + c) * nx * nx;
-        double t1[P::MAXNX], t2[P::MAXNX];
+        double qc[P::MAXNX];
+        if (s.kids_leaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[k] = -s.xl[c][k]; }   // q_leaf = -xbar_leaf (:578-582)
+        else if (s.kids_gleaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[k] = qg[(s.pos * d + c) * nx + k]; }
+        else { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[k] = ex[(tau * d + 1 + c) * nx + k]; }
+        const MatPtr W = M + dm.mW + (t * d + c) * nx * nx;
+        const MatPtr V = M + dm.mV + (t * d + c) * nu * nx;
         SPK_UNROLL for (int r = 0; r < nx; ++r) {
             double a = 0.;
-            SPK_UNROLL for (int k = 0; k < nu; ++k) a += Bw[r + k * nx] * s.dd[k];
-            t1[r] = a;
+            SPK_UNROLL for (int k = 0; k < nx; ++k) a += W[r + k * nx] * qc[k];
+            qi[r] += a;
         }
-        SPK_UNROLL for (int r = 0; r < nx; ++r) {
+        SPK_UNROLL for (int r = 0; r < nu; ++r) {
             double a = 0.;
-            SPK_UNROLL for (int k = 0; k < nx; ++k) a += Pc[r + k * nx] * t1[k];
-            t2[r] = a + qc[c][r];
-        }
-        SPK_UNROLL for (int col = 0; col < nx; ++col) {
-            double a = 0.;
-            SPK_UNROLL for (int r = 0; r < nx; ++r) a += Ab[r + col * nx] * t2[r];
-            qi[col] += a;
+            SPK_UNROLL for (int k = 0; k < nx; ++k) a += V[r + k * nu] * qc[k];
+            di[r] -= a;
         }
     }
-    const double *Kt = M + dm.mK + t * nu * nx;
-    SPK_UNROLL for (int col = 0; col < nx; ++col) {
-        double a = 0.;
-        SPK_UNROLL for (int r = 0; r < nu; ++r) a += Kt[r + col * nu] * (s.dd[r] - s.ub[r]);
-        qi[col] += a;
-    }
-    SPK_UNROLL for (int k = 0; k < nx; ++k) qi[k] -= s.xb[k];
+    SPK_UNROLL for (int k = 0; k < nu; ++k) s.dd[k] = di[k];
     if (s.lvl > 0) { SPK_UNROLL for (int k = 0; k < nx; ++k) ex[tau * nx + k] = qi[k]; }
     else if (q_out) { SPK_UNROLL for (int k = 0; k < nx; ++k) q_out[k] = qi[k]; }
 }
 
 // one level of the forward roll-out (implicit_l.jl:667-681).  xroot: x of the group root (x0 or the
-// value the crown stored), zo: zbar, receives x_i, u_i (and the children's x where they are group leaves).
+// value the crown stored).  Nothing is stored to global memory here: a store in front of the level's
+// barrier would make every level wait for its write acknowledgement; fwd_store() runs after the sweep.
 template <class P>
-SPK_DEV void fwd_node(const P &p, const Dims &dm, const double *M, int t, int tau, double *ex, const double *xroot,
-                      double *zo, TState<P> &s) {
+SPK_DEV void fwd_node(const P &p, const Dims &dm, MatPtr M, int t, int tau, double *ex,
+                      const double *xroot, TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
     double xi[P::MAXNX];
     if (s.lvl == 0) { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = xroot[k]; }
     else { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = ex[tau * nx + k]; }
-    const double *Kt = M + dm.mK + t * nu * nx;
-    SPK_UNROLL for (int r = 0; r < nu; ++r) {
-        double a = 0.;
-        SPK_UNROLL for (int k = 0; k < nx; ++k) a += Kt[r + k * nu] * xi[k];
-        s.ub[r] = a + s.dd[r];
-    }
     SPK_UNROLL for (int c = 0; c < d; ++c) {
-        const double *Bw = M + dm.mB + slot_event(c, d) * nx * nu;
-        const double *Ab = M + dm.mABK + ((t + 1) * d + c) * nx * nx;
-        const int j = s.c0 + c;
+        const MatPtr Bw = M + dm.mB + slot_event(c, d) * nx * nu;
+        const MatPtr Ab = M + dm.mABK + ((t + 1) * d + c) * nx * nx;
         SPK_UNROLL for (int r = 0; r < nx; ++r) {
             double a = 0., b2 = 0.;
             SPK_UNROLL for (int k = 0; k < nx; ++k) a += Ab[r + k * nx] * xi[k];
             SPK_UNROLL for (int k = 0; k < nu; ++k) b2 += Bw[r + k * nx] * s.dd[k];
             const double xc = a + b2;
-            if (s.kids_leaf) { s.xl[c][r] = xc; zo[dm.zx + j * nx + r] = xc; }
-            else if (s.kids_gleaf) zo[dm.zx + j * nx + r] = xc;
+            if (s.kids_gleaf) s.xl[c][r] = xc;       // group leaves: kept in registers, stored by fwd_store
             else ex[(tau * d + 1 + c) * nx + r] = xc;
         }
     }
-    SPK_UNROLL for (int k = 0; k < nx; ++k) { s.xb[k] = xi[k]; zo[dm.zx + s.node * nx + k] = xi[k]; }
+    const MatPtr Kt = M + dm.mK + t * nu * nx;
+    SPK_UNROLL for (int r = 0; r < nu; ++r) {
+        double a = 0.;
+        SPK_UNROLL for (int k = 0; k < nx; ++k) a += Kt[r + k * nu] * xi[k];
+        s.ub[r] = a + s.dd[r];
+    }
+    SPK_UNROLL for (int k = 0; k < nx; ++k) s.xb[k] = xi[k];
+}
+
+// after the forward sweep: x_i, u_i (and the x of children that are group leaves) -> zbar
+template <class P>
+SPK_DEV void fwd_store(const P &p, const Dims &dm, double *__restrict__ zo, const TState<P> &s) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d();
+    SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + s.node * nx + k] = s.xb[k];
     SPK_UNROLL for (int k = 0; k < nu; ++k) zo[dm.zu + s.node * nu + k] = s.ub[k];
+    if (s.kids_gleaf) {
+        SPK_UNROLL for (int c = 0; c < d; ++c) {
+            SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + (s.c0 + c) * nx + k] = s.xl[c][k];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // phase B, node-local.  zb = zbar (x_i, u_i and the leaf x_j come from the thread state unless
 // F_NO_SWEEP), z/v = the input iterate, vo = vbar.  mx[0..2] accumulate |xi_1|, |xi_2|, |xi| maxima.
 struct ProxScal {
-    double sigma, inv_sigma_neg, inv_gamma_neg;  // -1/sigma, -1/gamma as the reference forms them (cp.jl:73-75)
+    double sigma, inv_sigma;                     // 1/sigma: arg/sigma of prox_h_conj! as a multiplication
+    double inv_sigma_neg, inv_gamma_neg;         // -1/sigma, -1/gamma as the reference forms them (cp.jl:73-75)
     bool want_xi;                                // LOG-mode CP: xi = xi_1 + L' xi_2 (cp.jl:83-86)
 };
 
 template <class P>
-SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *z, const double *v, const double *zb,
-                     double *vo, TState<P> &s, const ProxScal &ps, unsigned flags, double *mx) {
+SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
+                     const double *__restrict__ v, const double *zb, double *__restrict__ vo, TState<P> &s,
+                     const ProxScal &ps, unsigned flags, double *mx) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu;
-    const double sg = ps.sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
+    const double sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0, wx = ps.want_xi;
     double m1 = mx[0], m2 = mx[1], m3 = mx[2];
     if (flags & F_NO_SWEEP) {
@@ -344,7 +361,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
 
     // ---- v1, v2 : risk-measure block of node i -------------------------------------------------
     {
-        const double *bb = M + dm.mb;
+        const MatPtr bb = M + dm.mb;
         double wy[P::MAXNY], dzy[P::MAXNY], t1[P::MAXNY], pr[P::MAXNY];
         double bw = 0., bdz = 0.;
         SPK_UNROLL for (int k = 0; k < ny; ++k) {
@@ -364,7 +381,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
             SPK_UNROLL for (int k = 0; k < ny; ++k) pr[k] = t1[k];
             nv2 = t2;
         } else {
-            SPK_UNROLL for (int k = 0; k < ny; ++k) { t1[k] = t1[k] / sg; pr[k] = t1[k]; }
+            SPK_UNROLL for (int k = 0; k < ny; ++k) { t1[k] = t1[k] * isg; pr[k] = t1[k]; }
             // projection onto the dual cone, sub-cone by sub-cone (implicit_l.jl:833-845)
             int off = 0;
             for (int cn = 0; cn < dm.n_cones; ++cn) {
@@ -376,7 +393,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
                 off += dim;
             }
             SPK_UNROLL for (int k = 0; k < ny; ++k) pr[k] = sg * (t1[k] - pr[k]);
-            t2 = t2 / sg;
+            t2 = t2 * isg;
             const double p2 = t2 >= 0. ? t2 : 0.;   // implicit_l.jl:849-851
             nv2 = sg * (t2 - p2);
         }
@@ -407,7 +424,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
             double t = sg * wv + vin, nvv;
             if (noprox) nvv = t;
             else {
-                t = t / sg;
+                t = t * isg;
                 const double pj = isx ? spk_clamp(t, dm.x_min, dm.x_max) : spk_clamp(t, dm.u_min, dm.u_max);
                 nvv = sg * (t - pj);
             }
@@ -421,33 +438,27 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
     // ---- per child j: (v6_j; v3_j, v4_j, v5_j) in SOC(nx+nu+2)  (implicit_l.jl:226-272, :854-900) ---
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = s.c0 + c, jn = j - 1;
-        const double *SQ = M + dm.mSqQ + (dm.nQ == 1 ? 0 : jn) * nx * nx;
-        const double *SR = M + dm.mSqR + (dm.nR == 1 ? 0 : jn) * nu * nu;
+        const MatPtr SQ = M + dm.mSqQ + (P::SHARED ? 0 : jn) * nx * nx;
+        const MatPtr SR = M + dm.mSqR + (P::SHARED ? 0 : jn) * nu * nu;
         double tt[P::MAXNX + P::MAXNU + 2], pj[P::MAXNX + P::MAXNU + 2], lz[P::MAXNX + P::MAXNU + 2];
         // tt/pj ordering = the reference's workspace: [v6, v3.., v4.., v5]; lz = L dz on the same entries
         const double zbt = zb[dm.zt + jn], zt_ = z[dm.zt + jn];
         const double wt = wz ? zbt : 2. * zbt + -1. * zt_, dzt = zbt - zt_;
+        sym_mv<P, false>(nx, SQ, wxv, tt + 1);
+        sym_mv<P, false>(nx, SQ, dzx, lz + 1);
+        sym_mv<P, false>(nu, SR, wuv, tt + 1 + nx);
+        sym_mv<P, false>(nu, SR, dzu, lz + 1 + nx);
         tt[0] = sg * (0.5 * wt) + v[dm.o6 + jn];
         lz[0] = 0.5 * dzt;
-        SPK_UNROLL for (int r = 0; r < nx; ++r) {
-            double a = 0., b2 = 0.;
-            SPK_UNROLL for (int k = 0; k < nx; ++k) { a += SQ[r + k * nx] * wxv[k]; b2 += SQ[r + k * nx] * dzx[k]; }
-            tt[1 + r] = sg * a + v[dm.o3 + jn * nx + r];
-            lz[1 + r] = b2;
-        }
-        SPK_UNROLL for (int r = 0; r < nu; ++r) {
-            double a = 0., b2 = 0.;
-            SPK_UNROLL for (int k = 0; k < nu; ++k) { a += SR[r + k * nu] * wuv[k]; b2 += SR[r + k * nu] * dzu[k]; }
-            tt[1 + nx + r] = sg * a + v[dm.o4 + jn * nu + r];
-            lz[1 + nx + r] = b2;
-        }
+        SPK_UNROLL for (int r = 0; r < nx; ++r) tt[1 + r] = sg * tt[1 + r] + v[dm.o3 + jn * nx + r];
+        SPK_UNROLL for (int r = 0; r < nu; ++r) tt[1 + nx + r] = sg * tt[1 + nx + r] + v[dm.o4 + jn * nu + r];
         tt[1 + nxu] = sg * (0.5 * wt) + v[dm.o5 + jn];
         lz[1 + nxu] = 0.5 * dzt;
         const int len = nxu + 2;
         if (noprox) {
             SPK_UNROLL for (int k = 0; k < len; ++k) pj[k] = tt[k];
         } else {
-            SPK_UNROLL for (int k = 0; k < len; ++k) tt[k] = tt[k] / sg;
+            SPK_UNROLL for (int k = 0; k < len; ++k) tt[k] = tt[k] * isg;
             tt[1 + nxu] -= 0.5;   // v5 -= 1/2, v6 += 1/2  (implicit_l.jl:928-933)
             tt[0] += 0.5;
             SPK_UNROLL for (int k = 0; k < len; ++k) pj[k] = tt[k];
@@ -463,16 +474,9 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
         tt[1 + nxu] = pj[1 + nxu] - v[dm.o5 + jn];
         SPK_UNROLL for (int k = 0; k < len; ++k) { lz[k] = lz[k] + nis * tt[k]; m2 = spk_max_nan(m2, fabs(lz[k])); }
         // L' contributions: x_i += sqrtQ dv3, u_i += sqrtR dv4 (implicit_l.jl:365-373, :412-420)
-        SPK_UNROLL for (int r = 0; r < nx; ++r) {
-            double a = 0., b2 = 0.;
-            SPK_UNROLL for (int k = 0; k < nx; ++k) { a += SQ[r + k * nx] * tt[1 + k]; b2 += SQ[r + k * nx] * lz[1 + k]; }
-            ltx[r] += a; lxx[r] += b2;
-        }
-        SPK_UNROLL for (int r = 0; r < nu; ++r) {
-            double a = 0., b2 = 0.;
-            SPK_UNROLL for (int k = 0; k < nu; ++k) { a += SR[r + k * nu] * tt[1 + nx + k]; b2 += SR[r + k * nu] * lz[1 + nx + k]; }
-            ltu[r] += a; lxu[r] += b2;
-        }
+        sym_mv<P, true>(nx, SQ, tt + 1, ltx);
+        sym_mv<P, true>(nu, SR, tt + 1 + nx, ltu);
+        if (wx) { sym_mv<P, true>(nx, SQ, lz + 1, lxx); sym_mv<P, true>(nu, SR, lz + 1 + nx, lxu); }
         // xi_1 on tau_j: 0.5 dv5 + 0.5 dv6 - dtau/gamma  (implicit_l.jl:432-437)
         const double x1t = (0.5 * tt[1 + nxu] + 0.5 * tt[0]) + nig * dzt;
         m1 = spk_max_nan(m1, fabs(x1t));
@@ -481,7 +485,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
         // ---- leaf child: (v13; v11, v12) in SOC(nx+2), v14 in the x box (implicit_l.jl:286-317, :752-810)
         if (s.kids_leaf) {
             const int li = j - dm.nn;
-            const double *SN = M + dm.mSqQN + (dm.nQN == 1 ? 0 : li) * nx * nx;
+            const MatPtr SN = M + dm.mSqQN + (P::SHARED ? 0 : li) * nx * nx;
             double wl[P::MAXNX], dl[P::MAXNX];
             SPK_UNROLL for (int k = 0; k < nx; ++k) {
                 const double zk = z[dm.zx + j * nx + k];
@@ -491,21 +495,18 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
             const double zbs = zb[dm.zs + j], zs_ = z[dm.zs + j];
             const double ws = wz ? zbs : 2. * zbs + -1. * zs_, dzs = zbs - zs_;
             double t3[P::MAXNX + 2], p3[P::MAXNX + 2], l3[P::MAXNX + 2];   // [v13, v11.., v12]
+            sym_mv<P, false>(nx, SN, wl, t3 + 1);
+            sym_mv<P, false>(nx, SN, dl, l3 + 1);
             t3[0] = sg * (0.5 * ws) + v[dm.o13 + li];
             l3[0] = 0.5 * dzs;
-            SPK_UNROLL for (int r = 0; r < nx; ++r) {
-                double a = 0., b2 = 0.;
-                SPK_UNROLL for (int k = 0; k < nx; ++k) { a += SN[r + k * nx] * wl[k]; b2 += SN[r + k * nx] * dl[k]; }
-                t3[1 + r] = sg * a + v[dm.o11 + li * nx + r];
-                l3[1 + r] = b2;
-            }
+            SPK_UNROLL for (int r = 0; r < nx; ++r) t3[1 + r] = sg * t3[1 + r] + v[dm.o11 + li * nx + r];
             t3[1 + nx] = sg * (0.5 * ws) + v[dm.o12 + li];
             l3[1 + nx] = 0.5 * dzs;
             const int l2 = nx + 2;
             if (noprox) {
                 SPK_UNROLL for (int k = 0; k < l2; ++k) p3[k] = t3[k];
             } else {
-                SPK_UNROLL for (int k = 0; k < l2; ++k) t3[k] = t3[k] / sg;
+                SPK_UNROLL for (int k = 0; k < l2; ++k) t3[k] = t3[k] * isg;
                 t3[1 + nx] -= 0.5;   // v12 -= 1/2, v13 += 1/2 (implicit_l.jl:934-939)
                 t3[0] += 0.5;
                 SPK_UNROLL for (int k = 0; k < l2; ++k) p3[k] = t3[k];
@@ -518,21 +519,22 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
             vo[dm.o12 + li] = p3[1 + nx];
             t3[1 + nx] = p3[1 + nx] - v[dm.o12 + li];
             SPK_UNROLL for (int k = 0; k < l2; ++k) { l3[k] = l3[k] + nis * t3[k]; m2 = spk_max_nan(m2, fabs(l3[k])); }
-            // v14 and the x_j, s_j residuals
+            // v14 and the x_j, s_j residuals: x_leaf = v14 + sqrtQN v11 (implicit_l.jl:376-396)
+            double a11[P::MAXNX], b11[P::MAXNX];
+            sym_mv<P, false>(nx, SN, t3 + 1, a11);
+            if (wx) sym_mv<P, false>(nx, SN, l3 + 1, b11);
             SPK_UNROLL for (int r = 0; r < nx; ++r) {
                 const double vin = v[dm.o14 + li * nx + r];
                 double t = sg * wl[r] + vin, nvv;
                 if (noprox) nvv = t;
-                else { t = t / sg; nvv = sg * (t - spk_clamp(t, dm.x_min, dm.x_max)); }
+                else { t = t * isg; nvv = sg * (t - spk_clamp(t, dm.x_min, dm.x_max)); }
                 vo[dm.o14 + li * nx + r] = nvv;
                 const double dv = nvv - vin;
                 const double x2 = dl[r] + nis * dv;
                 m2 = spk_max_nan(m2, fabs(x2));
-                double a = 0., b2 = 0.;
-                SPK_UNROLL for (int k = 0; k < nx; ++k) { a += SN[r + k * nx] * t3[1 + k]; b2 += SN[r + k * nx] * l3[1 + k]; }
-                const double x1 = (dv + a) + nig * dl[r];     // x_leaf = v14 + sqrtQN v11 (implicit_l.jl:376-396)
+                const double x1 = (dv + a11[r]) + nig * dl[r];
                 m1 = spk_max_nan(m1, fabs(x1));
-                if (wx) m3 = spk_max_nan(m3, fabs((x2 + b2) + x1));
+                if (wx) m3 = spk_max_nan(m3, fabs((x2 + b11[r]) + x1));
             }
             const double x1s = (0.5 * t3[1 + nx] + 0.5 * t3[0]) + nig * dzs;   // s_leaf (implicit_l.jl:445-448)
             m1 = spk_max_nan(m1, fabs(x1s));
@@ -557,16 +559,10 @@ SPK_DEV void b_local(const P &p, const Dims &dm, const double *M, const double *
 // Termination bookkeeping of run_cp! / should_terminate! (cp.jl:54-123, :205-228), run by ONE thread per
 // instance at the start of an iteration (for the previous one) and by the finalize kernel.
 // Returns true when the instance is finished.
-SPK_DEV bool ctl_prologue(Ctl &c, const double *partials, int n_groups, double *hist, int hist_cap, int parity,
+SPK_DEV bool ctl_prologue(Ctl &c, double x1, double x2, double x3, double *hist, int hist_cap, int parity,
                           bool start_next) {
     if (c.done) return true;
     if (c.pending) {
-        double x1 = 0., x2 = 0., x3 = 0.;
-        for (int g = 0; g < n_groups; ++g) {
-            x1 = spk_max_nan(x1, partials[g * kPartialStride + 0]);
-            x2 = spk_max_nan(x2, partials[g * kPartialStride + 1]);
-            x3 = spk_max_nan(x3, partials[g * kPartialStride + 2]);
-        }
         const bool log = (c.log_mode == 2);
         double xi = NAN;
         if (log) xi = (c.alg == 1) ? x3 : (x1 > x2 ? x1 : x2);   // cp.jl:83-86 / sp.jl:308

@@ -5,21 +5,30 @@
 //   X::barrier()    workgroup barrier (also orders the group's global-memory accesses)
 //   X::lds()        the q / x exchange buffer of the S1 sweeps
 //   X::flag()       one int shared by the workgroup
-//   X::reduce3(..)  NaN-propagating max over the workgroup of three per-thread values -> thread 0
+//   X::stash3 / reduce3 / red3(k)   NaN-propagating max over the workgroup of three per-thread values;
+//                   after reduce3() (which ends in a barrier) every thread can read the results
 // On the GPU (spock_kernels.hip) each() runs its body once for threadIdx.x and the state lives in
 // registers; the host emulation (tests/emu) loops over the threads.
 //
 // Kernel sequence of one CP iteration (driver: spock_abi.cpp, reference loop: cp.jl:205-228):
 //   no split (t0 == 0):  FULL
-//   split:               SUB_A (all subtrees)  ->  CROWN (one workgroup)  ->  SUB_B (all subtrees)
-// SUB_A : phase A on the subtree + backward sweep up to the subtree root (q_root, d_i to global memory)
-// CROWN : termination test of the PREVIOUS iteration, then phase A, backward and forward sweep and
-//         phase B on the crown (stages < t0); stores x at the subtree roots
-// SUB_B : forward sweep from the subtree root + phase B on the subtree; residual maxima per workgroup
+//   split:               SUB_A (nsub + 1 workgroups)  ->  CROWN (one workgroup)  ->  SUB_B (nsub + 1 workgroups)
+// SUB_A : workgroup g < nsub: phase A on subtree g + backward sweep up to its root (q_root, d_i to global
+//         memory); workgroup nsub: phase A on the crown (stages < t0), c_i / e_i to global memory
+// CROWN : termination test of the PREVIOUS iteration, then only the latency-critical part: backward and
+//         forward sweep through the crown; stores x at the subtree roots
+// SUB_B : workgroup g < nsub: forward sweep from the subtree root + phase B on the subtree;
+//         workgroup nsub: phase B on the crown; residual maxima per workgroup
 #pragma once
 #include "spock_device.hpp"
 
 namespace spock {
+
+SPK_DEV int group_threads_dev(int d, int stages) {   // non-leaf nodes of a complete d-ary tree with `stages` stages
+    int cnt = 0, lvl = 1;
+    for (int t = 0; t < stages - 1; ++t) { cnt += lvl; lvl *= d; }
+    return cnt;
+}
 
 template <class P, int MODE, class X>
 SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
@@ -30,13 +39,33 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     const int n_groups = dm.t0 > 0 ? dm.nsub + 1 : 1;
     double *partials = a.partials + (long)inst * n_groups * kPartialStride;
 
+    int stamp_idx = 0;
+    auto stamp = [&]() {
+        if ((flags & F_DBG_STAMPS) && a.dbg && inst == 0 && g == 0 && stamp_idx < 64) {
+            unsigned long long *d = a.dbg + ((long)(MODE == MODE_SUB_A ? 0 : (MODE == MODE_CROWN ? 1 : 2)) * 64 + stamp_idx) * 2;
+            x.each([&](int tid, TState<P> &) { if (tid == 0) x.clocks(d); });
+        }
+        ++stamp_idx;
+    };
+    stamp();   // 0: entry
+
     // ---- control: has this instance finished?  (FULL / CROWN also run the pending termination test)
     if (!(flags & F_NO_CTL)) {
         if (MODE == MODE_FULL || MODE == MODE_CROWN || MODE == MODE_FINALIZE) {
+            if (ctl.pending && !ctl.done) {   // workgroup-parallel max over the per-workgroup residual maxima
+                x.each([&](int tid, TState<P> &) {
+                    double mx[3] = {0., 0., 0.};
+                    for (int gg = tid; gg < n_groups; gg += x.nthreads()) {
+                        for (int k = 0; k < 3; ++k) mx[k] = spk_max_nan(mx[k], partials[gg * kPartialStride + k]);
+                    }
+                    x.stash3(tid, mx);
+                });
+                x.reduce3();
+            }
             x.each([&](int tid, TState<P> &) {
                 if (tid == 0) {
                     double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
-                    x.flag() = ctl_prologue(ctl, partials, n_groups, hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
+                    x.flag() = ctl_prologue(ctl, x.red3(0), x.red3(1), x.red3(2), hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
                 }
             });
             x.barrier();
@@ -46,9 +75,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         }
     }
     if (MODE == MODE_FINALIZE) return;
+    stamp();   // 1: control done
 
     const double gamma = ctl.gamma, sigma = ctl.sigma;
-    const double *M = a.mats;
+    const MatPtr M = (MatPtr)a.mats;
     const double *z = a.z_in + (long)inst * dm.nz;
     const double *v = a.v_in + (long)inst * dm.nv;
     double *zo = a.z_out + (long)inst * dm.nz;
@@ -56,28 +86,49 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     double *ex = x.lds();
 
     // ---- geometry of this group
-    const bool crown = (MODE == MODE_CROWN);
     const bool sub = (MODE == MODE_SUB_A || MODE == MODE_SUB_B);
-    const int root_stage = sub ? dm.t0 : 0;
-    const int root_pos = sub ? g : 0;
-    const int stages = sub ? dm.sub_stages : (crown ? dm.t0 + 1 : dm.N);
+    const bool crown_blk = sub && (g == dm.nsub);          // the extra workgroup of SUB_A / SUB_B
+    const bool crown = (MODE == MODE_CROWN) || crown_blk;
+    const int root_stage = (sub && !crown_blk) ? dm.t0 : 0;
+    const int root_pos = (sub && !crown_blk) ? g : 0;
+    const int stages = crown ? dm.t0 + 1 : (sub ? dm.sub_stages : dm.N);
     const int root_node = dm.first[root_stage] + root_pos;
+    const int nxu = p.nx() + p.nu();
+    double *cb = a.cbuf ? a.cbuf + (long)inst * group_threads_dev(p.d(), dm.t0 + 1) * nxu : nullptr;
     x.each([&](int tid, TState<P> &s) { init_geometry(p, dm, tid, root_stage, root_pos, stages, crown, s); });
 
     // ---- phase A (node-local)
-    if (MODE != MODE_SUB_B && !(flags & F_NO_ALOCAL)) {
+    if ((MODE == MODE_FULL || MODE == MODE_SUB_A) && !(flags & F_NO_ALOCAL)) {
         x.each([&](int, TState<P> &s) { if (s.active) a_local(p, dm, M, z, v, zo, s, gamma, flags); });
+        if (crown_blk) {
+            if (!(flags & F_NO_SWEEP))
+                x.each([&](int tid, TState<P> &s) {
+                    if (!s.active) return;
+                    for (int k = 0; k < p.nx(); ++k) cb[tid * nxu + k] = s.xb[k];
+                    for (int k = 0; k < p.nu(); ++k) cb[tid * nxu + p.nx() + k] = s.ub[k];
+                });
+            return;
+        }
     }
-    if (MODE == MODE_FULL || MODE == MODE_CROWN) x.barrier();   // zbar.s written by the parents is read in phase B
+    if (MODE == MODE_FULL) x.barrier();   // zbar.s written by the parents is read by the children in phase B
+    stamp();   // 2: phase A done
 
     // ---- S1 sweeps
-    if (!(flags & F_NO_SWEEP)) {
-        if (MODE != MODE_SUB_B) {
-            const double *qg = crown ? a.qroot + (long)inst * dm.nsub * dm.nx : nullptr;
+    if (!(flags & F_NO_SWEEP) && !crown_blk) {
+        if (MODE == MODE_CROWN) {
+            x.each([&](int tid, TState<P> &s) {
+                if (!s.active) return;
+                for (int k = 0; k < p.nx(); ++k) s.xb[k] = cb[tid * nxu + k];
+                for (int k = 0; k < p.nu(); ++k) s.ub[k] = cb[tid * nxu + p.nx() + k];
+            });
+        }
+        if (MODE != MODE_SUB_B && !(flags & F_DBG_NO_BWD)) {
+            const double *qg = (MODE == MODE_CROWN) ? a.qroot + (long)inst * dm.nsub * dm.nx : nullptr;
             double *q_out = (MODE == MODE_SUB_A) ? a.qroot + ((long)inst * dm.nsub + g) * dm.nx : nullptr;
             for (int l = stages - 2; l >= 0; --l) {
                 x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) bwd_node(p, dm, M, root_stage + l, tid, ex, qg, q_out, s); });
                 x.barrier();
+                stamp();   // one per backward level
             }
             if (MODE == MODE_SUB_A) {
                 double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
@@ -86,7 +137,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 });
             }
         }
-        if (MODE != MODE_SUB_A) {
+        if (MODE != MODE_SUB_A && !(flags & F_DBG_NO_FWD)) {
             if (MODE == MODE_SUB_B) {
                 const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
                 x.each([&](int, TState<P> &s) {
@@ -95,26 +146,33 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
             }
             const double *xroot = (MODE == MODE_SUB_B) ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
             for (int l = 0; l <= stages - 2; ++l) {
-                x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, M, root_stage + l, tid, ex, xroot, zo, s); });
+                x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, M, root_stage + l, tid, ex, xroot, s); });
                 x.barrier();
+                stamp();   // one per forward level
             }
+            x.each([&](int, TState<P> &s) { if (s.active) fwd_store(p, dm, zo, s); });
+            stamp();
         }
     }
 
     // ---- phase B (node-local) + residual maxima
-    if (MODE != MODE_SUB_A && !(flags & F_NO_BLOCAL)) {
+    if ((MODE == MODE_FULL || MODE == MODE_SUB_B) && !(flags & F_NO_BLOCAL)) {
         ProxScal ps;
         ps.sigma = sigma;
+        ps.inv_sigma = 1. / sigma;
         ps.inv_sigma_neg = -1. / sigma;
         ps.inv_gamma_neg = -1. / gamma;
         ps.want_xi = (ctl.log_mode == 2 && ctl.alg == 1);
+        const unsigned bflags = crown_blk ? (flags | F_NO_SWEEP) : flags;   // the crown's x, u come from zbar
         x.each([&](int tid, TState<P> &s) {
             double mx[3] = {0., 0., 0.};
-            if (s.active) b_local(p, dm, M, z, v, zo, vo, s, ps, flags, mx);
+            if (s.active) b_local(p, dm, M, z, v, zo, vo, s, ps, bflags, mx);
             x.stash3(tid, mx);
         });
-        const int slot = (MODE == MODE_SUB_B) ? g : (crown ? dm.nsub : 0);
-        x.reduce3(partials + (long)slot * kPartialStride);
+        const int slot = (MODE == MODE_SUB_B) ? g : 0;
+        x.reduce3();
+        x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + tid] = x.red3(tid); });
+        stamp();   // phase B done
     }
 }
 

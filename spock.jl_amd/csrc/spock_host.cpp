@@ -199,6 +199,13 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
         B[w] = Mat::from(hp.B.data() + (size_t)w * nx * nu, nx, nu);
     }
     std::vector<Mat> P(N), K(N - 1), Rinv(N - 1), ABK((size_t)N * d, Mat(nx, nx));
+    // Restructured recursion.  The reference computes, per non-leaf node i with children j (implicit_l.jl:584-637),
+    //   d_i = Rt^-1 (ubar_i - sum_j B_j' q_j),   q_i = sum_j ABK_j' (P_j B_j d_i + q_j) + K_i' (d_i - ubar_i) - xbar_i,
+    // a chain of five dependent mat-vecs per tree level.  Both are linear in (ubar_i, xbar_i, q_j); with
+    //   G = sum_j ABK_j' P_j B_j + K',  U = G Rt^-1 - K',  W_j = ABK_j' - G Rt^-1 B_j',  V_j = Rt^-1 B_j'
+    // they become  q_i = (U ubar_i - xbar_i) + sum_j W_j q_j  and  d_i = Rt^-1 ubar_i - sum_j V_j q_j:
+    // one mat-vec per level on the critical path, the bracketed terms are node-local.
+    std::vector<Mat> Um(N - 1), Wm((size_t)(N - 1) * d), Vm((size_t)(N - 1) * d);
     P[N - 1] = Mat::eye(nx);
     for (int t = N - 2; t >= 0; --t) {
         Mat sum_r(nu, nu), sum_k(nu, nx);
@@ -222,6 +229,22 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
             ABK[(size_t)(t + 1) * d + c] = abk;
         }
         P[t] = add(add(Mat::eye(nx), mul(T(K[t]), K[t])), sum_p);
+        Mat G = T(K[t]);
+        for (int c = 0; c < d; ++c) {
+            const int w = (2 + c) % d;
+            G = add(G, mul(mul(T(ABK[(size_t)(t + 1) * d + c]), P[t + 1]), B[w]));
+        }
+        const Mat GR = mul(G, Rinv[t]);
+        Mat negKt = T(K[t]);
+        for (auto &x : negKt.a) x = -x;
+        Um[t] = add(GR, negKt);
+        for (int c = 0; c < d; ++c) {
+            const int w = (2 + c) % d;
+            Mat GRB = mul(GR, T(B[w]));
+            for (auto &x : GRB.a) x = -x;
+            Wm[(size_t)t * d + c] = add(T(ABK[(size_t)(t + 1) * d + c]), GRB);
+            Vm[(size_t)t * d + c] = mul(Rinv[t], T(B[w]));
+        }
     }
 
     // ---- projector onto ker M, M = [E' -I -I ; F' 0 0]: Pi = I - M' (M M')^+ M (cpock.jl:71-81,125-128)
@@ -263,6 +286,12 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
     dm.mABK = (int)pool.size();
     out.ABK.clear();
     for (size_t k = 0; k < ABK.size(); ++k) { push(ABK[k].a); out.ABK.insert(out.ABK.end(), ABK[k].a.begin(), ABK[k].a.end()); }
+    dm.mU = (int)pool.size();
+    for (int t = 0; t < N - 1; ++t) push(Um[t].a);
+    dm.mW = (int)pool.size();
+    for (size_t k = 0; k < Wm.size(); ++k) push(Wm[k].a);
+    dm.mV = (int)pool.size();
+    for (size_t k = 0; k < Vm.size(); ++k) push(Vm[k].a);
     dm.mLs = push(ls.a);
     out.ls = ls.a;
     dm.mb = push(hp.b);
@@ -273,6 +302,13 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
     for (int k = 0; k < hp.nR; ++k) { Mat s = sym_sqrt(Mat::from(hp.R.data() + (size_t)k * nu * nu, nu, nu)); push(s.a); out.sqrtR.insert(out.sqrtR.end(), s.a.begin(), s.a.end()); }
     dm.mSqQN = (int)pool.size();
     for (int k = 0; k < hp.nQN; ++k) { Mat s = sym_sqrt(Mat::from(hp.QN.data() + (size_t)k * nx * nx, nx, nx)); push(s.a); out.sqrtQN.insert(out.sqrtQN.end(), s.a.begin(), s.a.end()); }
+    auto all_diag = [](const std::vector<double> &v, int n) {
+        const size_t cnt = v.size() / ((size_t)n * n);
+        for (size_t k = 0; k < cnt; ++k)
+            for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) if (i != j && v[k * n * n + (size_t)i + (size_t)j * n] != 0.) return false;
+        return true;
+    };
+    dm.diag_costs = (all_diag(out.sqrtQ, nx) && all_diag(out.sqrtR, nu) && all_diag(out.sqrtQN, nx)) ? 1 : 0;
     for (double x : pool) if (!(x == x)) return "build step produced NaN";
     return "";
 }

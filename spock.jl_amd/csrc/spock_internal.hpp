@@ -30,6 +30,10 @@ struct Dims {
     int first[kMaxStages + 1];  // first node of each stage (scenario_tree.jl:107)
     // offsets (in doubles) into the matrix pool
     int mB, mK, mRinv, mP, mABK, mLs, mb, mSqQ, mSqR, mSqQN;
+    // composite matrices of the restructured S1 recursion (spock_host.cpp): per stage t
+    //   U_t (nx x nu), per child slot W_{t,c} (nx x nx), V_{t,c} (nu x nx)
+    int mU, mW, mV;
+    int diag_costs;  // every sqrtQ / sqrtR / sqrtQN is diagonal -> element-wise products in the kernels
 };
 
 // Per-instance control block in device memory: the driver's scalars live here so that a captured
@@ -61,6 +65,9 @@ enum KFlags : unsigned {
     F_NO_PROX = 16u,     // phase B: v_out = sigma L w + v, no prox (operator L)
     F_NO_CTL = 32u,      // ignore the control block's done / pending logic (operators)
     F_NO_ALOCAL = 64u,   // skip phase A's node-local part (operator prox_h_conj)
+    F_DBG_NO_BWD = 128u, // measurement only (spock_profile_kernels + SPOCK_AMD_DEBUG_FLAGS): skip the backward sweep
+    F_DBG_NO_FWD = 256u, // measurement only: skip the forward sweep
+    F_DBG_STAMPS = 512u, // measurement only: thread 0 of every workgroup of instance 0 writes clock stamps to KArgs::dbg
 };
 
 struct KArgs {
@@ -70,10 +77,12 @@ struct KArgs {
     double *z_out, *v_out;      // zbar, vbar
     double *dbuf;               // [batch][nn*nu]      S1's d_i between phase A and phase B
     double *qroot;              // [batch][nsub*nx]    S1's q at the subtree roots
+    double *cbuf;               // [batch][crown non-leaf nodes][nx+nu]  node-local terms of the crown's sweep
     double *partials;           // [batch][(nsub+1)*kPartialStride]
     Ctl *ctl;                   // [batch]
     const double *x0;           // [batch][nx]
     double *hist;               // [batch][hist_cap*kHistStride]
+    unsigned long long *dbg;    // [3 kernels][64 stamps][2]: (s_memtime, s_memrealtime) pairs, diagnostic builds of the timing only
     int hist_cap;
     int parity;
     unsigned flags;

@@ -22,9 +22,12 @@ struct GpuExec {
     __device__ __forceinline__ double *lds() { return ex; }
     __device__ __forceinline__ int &flag() { return *fl; }
     __device__ __forceinline__ void stash3(int, const double *mx) { m[0] = mx[0]; m[1] = mx[1]; m[2] = mx[2]; }
+    __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
+    __device__ __forceinline__ void clocks(unsigned long long *d) { d[0] = __builtin_readcyclecounter(); d[1] = __builtin_amdgcn_s_memrealtime(); }
     // values are |.| (sign bit clear) or NaN: the unsigned order of the bit patterns is the
     // NaN-propagating max order, so an integer max does the reduction
-    __device__ __forceinline__ void reduce3(double *dst) {
+    __device__ __forceinline__ void reduce3() {
+        __syncthreads();
         if (threadIdx.x < 3) red[threadIdx.x] = 0ull;
         __syncthreads();
 #pragma unroll
@@ -38,8 +41,8 @@ struct GpuExec {
             if ((threadIdx.x & 63) == 0) atomicMax(&red[k], b);
         }
         __syncthreads();
-        if (threadIdx.x < 3) dst[threadIdx.x] = __longlong_as_double((long long)red[threadIdx.x]);
     }
+    __device__ __forceinline__ double red3(int k) const { return __longlong_as_double((long long)red[k]); }
 };
 
 template <class P, int MODE>
@@ -57,14 +60,15 @@ static inline int round64(int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; }
 template <class P>
 static int launch_variant(int mode, const KArgs &a, hipStream_t st) {
     const Dims &dm = a.dm;
-    int stages, gx;
+    int nthr, gx;
+    const int sub_thr = group_threads(dm.d, dm.sub_stages), crown_thr = group_threads(dm.d, dm.t0 + 1);
     switch (mode) {
-        case MODE_FULL: stages = dm.N; gx = 1; break;
-        case MODE_SUB_A: case MODE_SUB_B: stages = dm.sub_stages; gx = dm.nsub; break;
-        case MODE_CROWN: stages = dm.t0 + 1; gx = 1; break;
-        default: stages = 2; gx = 1; break;
+        case MODE_FULL: nthr = group_threads(dm.d, dm.N); gx = 1; break;
+        case MODE_SUB_A: case MODE_SUB_B: nthr = sub_thr > crown_thr ? sub_thr : crown_thr; gx = dm.nsub + 1; break;
+        case MODE_CROWN: nthr = crown_thr; gx = 1; break;
+        default: nthr = 64; gx = 1; break;
     }
-    const int thr = mode == MODE_FINALIZE ? 64 : round64(group_threads(dm.d, stages));
+    const int thr = round64(nthr);
     if (thr > 512) return (int)hipErrorInvalidConfiguration;
     const size_t lds = ((size_t)thr * dm.nx + 4) * sizeof(double);
     const dim3 grid(gx, a.batch), block(thr);
@@ -92,11 +96,14 @@ bool have_static_variant(int nx, int nu, int d, int ny) {
 int launch_group(int mode, const KArgs &a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const Dims &dm = a.dm;
-#define X(a_, b_, c_, e_) \
-    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_) return launch_variant<StaticDims<a_, b_, c_, e_>>(mode, a, st);
+    const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
+#define X(a_, b_, c_, e_)                                                                      \
+    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                                \
+        return cm == 2 ? launch_variant<StaticDims<a_, b_, c_, e_, 2>>(mode, a, st) : cm == 1 ? launch_variant<StaticDims<a_, b_, c_, e_, 1>>(mode, a, st)    \
+                             : launch_variant<StaticDims<a_, b_, c_, e_, 0>>(mode, a, st);
     SPOCK_STATIC_SHAPES(X)
 #undef X
-    return launch_variant<DynDims>(mode, a, st);
+    return cm == 2 ? launch_variant<DynDims<2>>(mode, a, st) : cm == 1 ? launch_variant<DynDims<1>>(mode, a, st) : launch_variant<DynDims<0>>(mode, a, st);
 }
 
 }  // namespace spock

@@ -52,13 +52,28 @@ def _ptr(a):
 
 
 class _SolverState:
-    """model.solver_state: nz, nv, L_norm and the iterate z, v (host copies refreshed after every solve)."""
+    """model.solver_state: nz, nv, L_norm and the iterate z, v.  The iterate lives on the GPU; ``z`` / ``v`` copy it
+    out on first access after a solve (shape [nz] / [nv], or [batch, .] for batch > 1)."""
 
-    def __init__(self, nz, nv, L_norm, batch):
+    def __init__(self, model, nz, nv, L_norm):
+        self._model = model
         self.nz, self.nv, self.L_norm = nz, nv, L_norm
-        shape_z, shape_v = ((nz,), (nv,)) if batch == 1 else ((batch, nz), (batch, nv))
-        self.z = np.zeros(shape_z)
-        self.v = np.zeros(shape_v)
+        self._z = self._v = None
+
+    def _invalidate(self):
+        self._z = self._v = None
+
+    @property
+    def z(self):
+        if self._z is None:
+            self._z = self._model._fetch("z")
+        return self._z
+
+    @property
+    def v(self):
+        if self._v is None:
+            self._v = self._model._fetch("v")
+        return self._v
 
 
 class _SolverStateInternal:
@@ -100,7 +115,7 @@ class Model:
         self.sizes = sz
         assert sz.nz == flat.nz and sz.nv == flat.nv
         default_L = 10.0 if options.algorithm == AlgorithmOptions.CP else 3.28
-        self.solver_state = _SolverState(sz.nz, sz.nv, default_L if L_norm is None else float(L_norm), self.batch)
+        self.solver_state = _SolverState(self, sz.nz, sz.nv, default_L if L_norm is None else float(L_norm))
         self.solver_state_internal = _SolverStateInternal(flat)
         self.results = []
 
@@ -116,12 +131,15 @@ class Model:
             pass
 
     # ---- state
+    def _fetch(self, which):
+        n = self.sizes.nz if which == "z" else self.sizes.nv
+        out = np.empty((self.batch, n))
+        fn = self._lib.spock_get_z if which == "z" else self._lib.spock_get_v
+        _lib.check(self._lib, fn(self._h, _ptr(out)))
+        return out[0] if self.batch == 1 else out
+
     def _refresh(self):
-        z = np.empty((self.batch, self.sizes.nz)); v = np.empty((self.batch, self.sizes.nv))
-        _lib.check(self._lib, self._lib.spock_get_z(self._h, _ptr(z)))
-        _lib.check(self._lib, self._lib.spock_get_v(self._h, _ptr(v)))
-        self.solver_state.z = z[0] if self.batch == 1 else z
-        self.solver_state.v = v[0] if self.batch == 1 else v
+        self.solver_state._invalidate()
 
     def set_state(self, z, v):
         z = np.ascontiguousarray(np.broadcast_to(np.asarray(z, dtype=np.float64).reshape(-1, self.sizes.nz), (self.batch, self.sizes.nz)))
@@ -152,6 +170,13 @@ class Model:
         ms = C.c_double(0.); it = C.c_int32(0)
         _lib.check(self._lib, self._lib.spock_get_timing(self._h, C.byref(ms), C.byref(it)))
         return ms.value, it.value
+
+    def profile_kernels(self, reps: int = 50):
+        """Average HIP-event duration (ms) per kernel kind over `reps` extra iterations:
+        {"sub_a", "crown", "sub_b", "full"} -> (avg_ms, launches)."""
+        ms = np.zeros(4); n = np.zeros(4, dtype=np.int32)
+        _lib.check(self._lib, self._lib.spock_profile_kernels(self._h, int(reps), _ptr(ms), _ptr(n)))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(("sub_a", "crown", "sub_b", "full"))}
 
     # ---- operator-level seam (single instance): L!, L_transpose!, prox_f!, prox_h_conj!, spock_dot
     def L(self, z):

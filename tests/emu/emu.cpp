@@ -26,23 +26,26 @@ struct EmuExec {
     std::vector<TState<P>> st;
     std::vector<double> ex;
     std::vector<std::array<double, 3>> m;
-    int fl = 0, nthreads = 0;
+    int fl = 0, nthreads_v = 0;
     bool reverse = false;
-    EmuExec(int thr, int nx) : st(thr), ex((size_t)thr * nx + 8, 0.), m(thr), nthreads(thr), reverse(env_on("SPOCK_EMU_REVERSE")) {}
+    EmuExec(int thr, int nx) : st(thr), ex((size_t)thr * nx + 8, 0.), m(thr), nthreads_v(thr), reverse(env_on("SPOCK_EMU_REVERSE")) {}
     template <class F>
     void each(F &&f) {
-        if (!reverse) for (int t = 0; t < nthreads; ++t) f(t, st[t]);
-        else for (int t = nthreads - 1; t >= 0; --t) f(t, st[t]);
+        if (!reverse) for (int t = 0; t < nthreads_v; ++t) f(t, st[t]);
+        else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t]);
     }
     void barrier() {}
     double *lds() { return ex.data(); }
     int &flag() { return fl; }
     void stash3(int tid, const double *mx) { m[tid] = {mx[0], mx[1], mx[2]}; }
-    void reduce3(double *dst) {
-        double r[3] = {0., 0., 0.};
-        for (int t = 0; t < nthreads; ++t) for (int k = 0; k < 3; ++k) r[k] = spk_max_nan(r[k], m[t][k]);
-        for (int k = 0; k < 3; ++k) dst[k] = r[k];
+    double r3[3] = {0., 0., 0.};
+    int nthreads() const { return nthreads_v; }
+    void clocks(unsigned long long *d) { d[0] = 0; d[1] = 0; }
+    void reduce3() {
+        for (int k = 0; k < 3; ++k) r3[k] = 0.;
+        for (int t = 0; t < nthreads_v; ++t) for (int k = 0; k < 3; ++k) r3[k] = spk_max_nan(r3[k], m[t][k]);
     }
+    double red3(int k) const { return r3[k]; }
 };
 
 static inline int round64(int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; }
@@ -59,14 +62,15 @@ static void run_blocks(const KArgs &a, int gx, int thr) {
 template <class P>
 static int launch_variant(int mode, const KArgs &a) {
     const Dims &dm = a.dm;
-    int stages, gx;
+    int nthr, gx;
+    const int sub_thr = group_threads(dm.d, dm.sub_stages), crown_thr = group_threads(dm.d, dm.t0 + 1);
     switch (mode) {
-        case MODE_FULL: stages = dm.N; gx = 1; break;
-        case MODE_SUB_A: case MODE_SUB_B: stages = dm.sub_stages; gx = dm.nsub; break;
-        case MODE_CROWN: stages = dm.t0 + 1; gx = 1; break;
-        default: stages = 2; gx = 1; break;
+        case MODE_FULL: nthr = group_threads(dm.d, dm.N); gx = 1; break;
+        case MODE_SUB_A: case MODE_SUB_B: nthr = sub_thr > crown_thr ? sub_thr : crown_thr; gx = dm.nsub + 1; break;
+        case MODE_CROWN: nthr = crown_thr; gx = 1; break;
+        default: nthr = 64; gx = 1; break;
     }
-    const int thr = mode == MODE_FINALIZE ? 64 : round64(group_threads(dm.d, stages));
+    const int thr = round64(nthr);
     if (thr > 512) return 9;
     switch (mode) {
         case MODE_FULL: run_blocks<P, MODE_FULL>(a, gx, thr); break;
@@ -90,13 +94,16 @@ bool have_static_variant(int nx, int nu, int d, int ny) {
 
 int launch_group(int mode, const KArgs &a, void *) {
     const Dims &dm = a.dm;
+    const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
     if (!env_on("SPOCK_EMU_FORCE_DYN")) {
-#define X(a_, b_, c_, e_) \
-    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_) return launch_variant<StaticDims<a_, b_, c_, e_>>(mode, a);
+#define X(a_, b_, c_, e_)                                                                  \
+    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                            \
+        return cm == 2 ? launch_variant<StaticDims<a_, b_, c_, e_, 2>>(mode, a) : cm == 1 ? launch_variant<StaticDims<a_, b_, c_, e_, 1>>(mode, a)    \
+                             : launch_variant<StaticDims<a_, b_, c_, e_, 0>>(mode, a);
         SPOCK_STATIC_SHAPES(X)
 #undef X
     }
-    return launch_variant<DynDims>(mode, a);
+    return cm == 2 ? launch_variant<DynDims<2>>(mode, a) : cm == 1 ? launch_variant<DynDims<1>>(mode, a) : launch_variant<DynDims<0>>(mode, a);
 }
 
 // ---- spock_rt.hpp on host memory ---------------------------------------------------------------------
