@@ -39,6 +39,10 @@ struct spock_handle_s {
     double *o_z[2] = {nullptr, nullptr}, *o_v[2] = {nullptr, nullptr}, *o_dbuf = nullptr, *o_qroot = nullptr,
            *o_cbuf = nullptr, *o_partials = nullptr, *o_x0 = nullptr;
     Ctl *o_ctl = nullptr;
+    // SP (SuperMann) state: ten [batch][nz+nv] vectors, the circular Anderson buffers, per-instance scalars
+    double *s_vec[10] = {nullptr}, *s_MP = nullptr, *s_Q = nullptr, *s_partF = nullptr, *s_partL = nullptr;
+    SpCtl *s_ctl = nullptr;
+    std::vector<SpCtl> h_sp;
     std::vector<Ctl> h_ctl;
     double last_ms = 0.;
     int last_iters = 0;
@@ -78,6 +82,7 @@ KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
         a.dbuf = h->o_dbuf; a.qroot = h->o_qroot; a.cbuf = h->o_cbuf; a.partials = h->o_partials; a.ctl = h->o_ctl; a.x0 = h->o_x0;
         a.hist = nullptr; a.hist_cap = 0; a.batch = 1;
     }
+    a.stride_z = h->bp.dm.nz; a.stride_v = h->bp.dm.nv;
     a.parity = parity;
     a.flags = flags;
     return a;
@@ -140,6 +145,131 @@ int run_op(spock_handle_s *h, const double *z_in, const double *v_in, const doub
     return SPOCK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// SP driver (run_sp!, src/model_algorithms/sp.jl:358-469): see spock_sp.hpp for the kernel sequence
+enum { SV_Z = 0, SV_ZB, SV_ZOLD, SV_R, SV_ROLD, SV_DP, SV_W, SV_WB, SV_RW, SV_D };
+
+SpArgs make_sp_args(spock_handle_s *h, int op) {
+    SpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const Dims &dm = h->bp.dm;
+    a.dm = dm; a.mats = h->d_mats; a.ctl = h->d_ctl; a.sp = h->s_ctl;
+    a.Z = h->s_vec[SV_Z]; a.ZB = h->s_vec[SV_ZB]; a.ZOLD = h->s_vec[SV_ZOLD]; a.R = h->s_vec[SV_R]; a.ROLD = h->s_vec[SV_ROLD];
+    a.DP = h->s_vec[SV_DP]; a.W = h->s_vec[SV_W]; a.WB = h->s_vec[SV_WB]; a.RW = h->s_vec[SV_RW]; a.D = h->s_vec[SV_D];
+    a.MP = h->s_MP; a.Q = h->s_Q; a.partF = h->s_partF; a.partL = h->s_partL;
+    a.hist = h->d_hist; a.hist_cap = h->hist_cap;
+    a.nr = (long)dm.nz + dm.nv;
+    a.n_partF = sp_flat_blocks(a.nr); a.n_partL = sp_lop_blocks(dm);
+    a.batch = h->batch; a.op = op;
+    return a;
+}
+
+// T(in) -> out on the concatenated z|v vectors with the CP kernels (no CP termination logic: F_SP)
+int launch_sp_T(spock_handle_s *h, double *in, double *out) {
+    const Dims &dm = h->bp.dm;
+    KArgs a = make_args(h, false, 0, F_SP);
+    a.z_in = in; a.v_in = in + dm.nz; a.z_out = out; a.v_out = out + dm.nz;
+    a.stride_z = a.stride_v = (long)dm.nz + dm.nv;
+    a.hist = nullptr; a.hist_cap = 0;
+    if (dm.t0 == 0) return launch_group(MODE_FULL, a, h->stream);
+    int e = launch_group(MODE_SUB_A, a, h->stream);
+    if (!e) e = launch_group(MODE_CROWN, a, h->stream);
+    if (!e) e = launch_group(MODE_SUB_B, a, h->stream);
+    return e;
+}
+
+int launch_sp_iteration(spock_handle_s *h) {
+    int e = launch_sp_T(h, h->s_vec[SV_Z], h->s_vec[SV_ZB]);
+    const int seq1[] = {SP_FLAT1, SP_LOP_R, SP_CTL_A, SP_FLAT2, SP_CTL_B, SP_FLAT3};
+    for (int op : seq1) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
+    if (!e) e = launch_sp_T(h, h->s_vec[SV_W], h->s_vec[SV_WB]);
+    const int seq2[] = {SP_FLAT4, SP_LOP_RT, SP_CTL_C, SP_FLAT5, SP_LOP_DP, SP_CTL_D};
+    for (int op : seq2) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
+    return e;
+}
+
+// initial values of build_spock (src/models/spock.jl:83-201): z = v = 0, z_old = v_old = rz_old = rv_old = 1,
+// MP = Q = 0, aa_R = I, everything else 0
+int sp_init_state(spock_handle_s *h) {
+    const Dims &dm = h->bp.dm;
+    const size_t B = (size_t)h->batch, nr = (size_t)dm.nz + dm.nv;
+    for (int k = 0; k < 10; ++k) { int e = rt::dzero(h->s_vec[k], B * nr * sizeof(double), h->stream); if (e) return e; }
+    std::vector<double> ones(B * nr, 1.0);
+    int e = rt::h2d(h->s_vec[SV_ZOLD], ones.data(), B * nr * sizeof(double), h->stream);
+    if (!e) e = rt::h2d(h->s_vec[SV_ROLD], ones.data(), B * nr * sizeof(double), h->stream);
+    if (!e) e = rt::dzero(h->s_MP, B * 3 * nr * sizeof(double), h->stream);
+    if (!e) e = rt::dzero(h->s_Q, B * 3 * nr * sizeof(double), h->stream);
+    SpCtl c;
+    std::memset(&c, 0, sizeof(c));
+    c.R[0] = c.R[4] = c.R[8] = 1.;
+    c.r_safe = INFINITY;
+    h->h_sp.assign(B, c);
+    if (!e) e = rt::h2d(h->s_ctl, h->h_sp.data(), B * sizeof(SpCtl), h->stream);
+    if (!e) e = rt::sync(h->stream);
+    return e;
+}
+
+int sp_solve(spock_handle_s *h, const double *x0, double tol, int verbose, const double *z0, const double *v0,
+             double gamma, double sigma, spock_result_t *results) {
+    const Dims &dm = h->bp.dm;
+    const size_t B = (size_t)h->batch, nr = (size_t)dm.nz + dm.nv;
+    RTCHECK(rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream));
+    if (z0) {
+        for (size_t b = 0; b < B; ++b) {
+            RTCHECK(rt::h2d(h->s_vec[SV_Z] + b * nr, z0 + b * dm.nz, sizeof(double) * dm.nz, h->stream));
+            RTCHECK(rt::h2d(h->s_vec[SV_Z] + b * nr + dm.nz, v0 + b * dm.nv, sizeof(double) * dm.nv, h->stream));
+        }
+    }
+    h->h_ctl.assign(B, fresh_ctl(h, gamma, sigma, tol, verbose));
+    RTCHECK(rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream));
+    // per-solve locals of run_sp! (sp.jl:383-389): Anderson counter and r_safe restart, R / head / buffers persist
+    RTCHECK(rt::d2h(h->h_sp.data(), h->s_ctl, B * sizeof(SpCtl), h->stream));
+    RTCHECK(rt::sync(h->stream));
+    for (auto &c : h->h_sp) { c.k = 0; c.r_safe = INFINITY; c.rnorm = INFINITY; c.rtilde = INFINITY; c.accept = 0; c.backtrack = 0; }
+    RTCHECK(rt::h2d(h->s_ctl, h->h_sp.data(), B * sizeof(SpCtl), h->stream));
+
+    const int G = h->graph_iters > 0 ? h->graph_iters : -h->graph_iters;
+    const bool use_graph = h->graph_iters > 0 && rt::graphs_supported();
+    if (use_graph && !h->graph) {
+        RTCHECK(rt::capture_begin(h->stream));
+        int e = 0;
+        for (int it = 0; it < G && e == 0; ++it) e = launch_sp_iteration(h);
+        void *exec = nullptr;
+        const int e2 = rt::capture_end(h->stream, &exec);
+        if (e) return fail(SPOCK_ERR_HIP, std::string("kernel launch during capture: ") + rt::err(e));
+        if (e2) return fail(SPOCK_ERR_HIP, std::string("hipStreamEndCapture/hipGraphInstantiate: ") + rt::err(e2));
+        h->graph = exec;
+    }
+    RTCHECK(rt::event_record(h->ev0, h->stream));
+    const int max_reps = (h->max_iter + 1 + G - 1) / G + 2;
+    bool all_done = false;
+    for (int rep = 0; rep < max_reps && !all_done; ++rep) {
+        if (use_graph) RTCHECK(rt::graph_launch(h->graph, h->stream));
+        else for (int it = 0; it < G; ++it) RTCHECK(launch_sp_iteration(h));
+        RTCHECK(rt::d2h(h->h_ctl.data(), h->d_ctl, B * sizeof(Ctl), h->stream));
+        RTCHECK(rt::sync(h->stream));
+        all_done = true;
+        for (const Ctl &c : h->h_ctl) all_done = all_done && c.done;
+    }
+    RTCHECK(rt::event_record(h->ev1, h->stream));
+    RTCHECK(rt::sync(h->stream));
+    float ms = 0.f;
+    RTCHECK(rt::event_elapsed(&ms, h->ev0, h->ev1));
+    if (!all_done) return fail(SPOCK_ERR_HIP, "driver did not terminate (internal error)");
+    int evals = 0;
+    for (size_t b = 0; b < B; ++b) {
+        const Ctl &c = h->h_ctl[b];
+        if (c.evals > evals) evals = c.evals;
+        if (results) {
+            spock_result_t &r = results[b];
+            r.status = c.status; r.iterations = c.evals; r.iter_ref = c.iter; r.reserved = 0;
+            r.xi1 = c.xi1; r.xi2 = c.xi2; r.xi = c.xi; r.solve_ms = ms;
+        }
+    }
+    h->last_ms = ms; h->last_iters = evals;
+    return SPOCK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -156,7 +286,6 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     if (p->N < 2 || p->N > kMaxStages || p->nx < 1 || p->nu < 1 || p->ny < 1) return fail(SPOCK_ERR_BAD_ARG, "invalid N / nx / nu / ny");
     const int alg = o && o->algorithm ? o->algorithm : SPOCK_ALG_CP;
     if (alg != SPOCK_ALG_CP && alg != SPOCK_ALG_SP) return fail(SPOCK_ERR_UNSUPPORTED, "This combination of solver options is not supported.");  // model.jl:295
-    if (alg == SPOCK_ALG_SP) return fail(SPOCK_ERR_UNSUPPORTED, "SP (SuperMann) driver is not on the GPU path yet; use SPOCK_ALG_CP");
 
     spock_handle_s *h = new spock_handle_s();
     HostProblem &hp = h->hp;
@@ -198,7 +327,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     h->max_iter = o && o->max_iter > 0 ? o->max_iter : (alg == SPOCK_ALG_CP ? 5000 : 1000);                          // cp.jl:190, sp.jl:360
     int gi = o ? o->graph_iters : 0;
     if (const char *e = std::getenv("SPOCK_AMD_GRAPH_ITERS")) gi = std::atoi(e);
-    if (gi == 0) gi = 32;
+    if (gi == 0) gi = (alg == SPOCK_ALG_SP) ? 8 : 32;
     if (gi > 0 && (gi & 1)) gi += 1;   // an even count brings the ping-pong parity back to 0
     h->graph_iters = gi;
     int split = o ? o->split_stage : 0;
@@ -221,8 +350,17 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     const size_t B = (size_t)h->batch;
     if ((e = dev_alloc(h, &h->d_mats, h->bp.mats.size()))) return bail(e, "hipMalloc(matrix pool)");
     if ((e = rt::h2d(h->d_mats, h->bp.mats.data(), h->bp.mats.size() * sizeof(double), h->stream))) return bail(e, "upload");
-    for (int k = 0; k < 2; ++k) {
-        if ((e = dev_alloc(h, &h->d_z[k], B * dm.nz)) || (e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
+    if (alg == SPOCK_ALG_CP) {
+        for (int k = 0; k < 2; ++k) {
+            if ((e = dev_alloc(h, &h->d_z[k], B * dm.nz)) || (e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
+        }
+    } else {
+        const size_t nr = (size_t)dm.nz + dm.nv;
+        for (int k = 0; k < 10; ++k) if ((e = dev_alloc(h, &h->s_vec[k], B * nr))) return bail(e, "hipMalloc(SP state)");
+        if ((e = dev_alloc(h, &h->s_MP, B * 3 * nr)) || (e = dev_alloc(h, &h->s_Q, B * 3 * nr)) ||
+            (e = dev_alloc(h, &h->s_partF, B * (size_t)sp_flat_blocks((long)nr) * kSpSums)) ||
+            (e = dev_alloc(h, &h->s_partL, B * (size_t)sp_lop_blocks(dm) * kSpSums)) || (e = dev_alloc(h, &h->s_ctl, B)))
+            return bail(e, "hipMalloc(SP state)");
     }
     h->hist_cap = h->max_iter + 2;
     if ((e = dev_alloc(h, &h->d_dbuf, B * dm.nn * dm.nu)) || (e = dev_alloc(h, &h->d_qroot, B * dm.nsub * dm.nx)) ||
@@ -234,6 +372,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     h->h_ctl.assign(B, fresh_ctl(h, 0., 0., 0., SPOCK_SILENT));
     for (auto &c : h->h_ctl) c.done = 1;
     if ((e = rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream))) return bail(e, "upload");
+    if (alg == SPOCK_ALG_SP && (e = sp_init_state(h))) return bail(e, "SP state initialisation");
     if ((e = rt::sync(h->stream))) return bail(e, "hipStreamSynchronize");
     *out = h;
     return SPOCK_OK;
@@ -273,6 +412,7 @@ int spock_solve(spock_handle_t h, const double *x0, double tol, int32_t verbose,
     if (!(std::isfinite(gamma) && std::isfinite(sigma))) { sigma = 0.99 / std::sqrt(h->L_norm); gamma = sigma; }  // cp.jl:198-201
     if (!(gamma > 0. && sigma > 0.)) return fail(SPOCK_ERR_BAD_ARG, "gamma and sigma must be positive");
 
+    if (h->alg == SPOCK_ALG_SP) return sp_solve(h, x0, tol, verbose, z0, v0, gamma, sigma, results);
     RTCHECK(rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream));
     if (z0) {
         RTCHECK(rt::h2d(h->d_z[0], z0, B * dm.nz * sizeof(double), h->stream));
@@ -333,18 +473,41 @@ int spock_solve(spock_handle_t h, const double *x0, double tol, int32_t verbose,
 
 int spock_get_z(spock_handle_t h, double *z_out) {
     if (!h || !z_out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    if (h->alg == SPOCK_ALG_SP) {
+        const size_t nr = (size_t)h->bp.dm.nz + h->bp.dm.nv;
+        for (int b = 0; b < h->batch; ++b)
+            RTCHECK(rt::d2h(z_out + (size_t)b * h->bp.dm.nz, h->s_vec[0] + b * nr, sizeof(double) * h->bp.dm.nz, h->stream));
+        RTCHECK(rt::sync(h->stream));
+        return SPOCK_OK;
+    }
     RTCHECK(rt::d2h(z_out, h->d_z[0], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
 }
 int spock_get_v(spock_handle_t h, double *v_out) {
     if (!h || !v_out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    if (h->alg == SPOCK_ALG_SP) {
+        const size_t nr = (size_t)h->bp.dm.nz + h->bp.dm.nv;
+        for (int b = 0; b < h->batch; ++b)
+            RTCHECK(rt::d2h(v_out + (size_t)b * h->bp.dm.nv, h->s_vec[0] + b * nr + h->bp.dm.nz, sizeof(double) * h->bp.dm.nv, h->stream));
+        RTCHECK(rt::sync(h->stream));
+        return SPOCK_OK;
+    }
     RTCHECK(rt::d2h(v_out, h->d_v[0], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
 }
 int spock_set_state(spock_handle_t h, const double *z, const double *v) {
     if (!h || !z || !v) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    if (h->alg == SPOCK_ALG_SP) {
+        const size_t nr = (size_t)h->bp.dm.nz + h->bp.dm.nv;
+        for (int b = 0; b < h->batch; ++b) {
+            RTCHECK(rt::h2d(h->s_vec[0] + b * nr, z + (size_t)b * h->bp.dm.nz, sizeof(double) * h->bp.dm.nz, h->stream));
+            RTCHECK(rt::h2d(h->s_vec[0] + b * nr + h->bp.dm.nz, v + (size_t)b * h->bp.dm.nv, sizeof(double) * h->bp.dm.nv, h->stream));
+        }
+        RTCHECK(rt::sync(h->stream));
+        return SPOCK_OK;
+    }
     RTCHECK(rt::h2d(h->d_z[0], z, (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
     RTCHECK(rt::h2d(h->d_v[0], v, (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
     RTCHECK(rt::sync(h->stream));
@@ -352,6 +515,7 @@ int spock_set_state(spock_handle_t h, const double *z, const double *v) {
 }
 int spock_reset(spock_handle_t h) {
     if (!h) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    if (h->alg == SPOCK_ALG_SP) { RTCHECK(sp_init_state(h)); return SPOCK_OK; }
     for (int k = 0; k < 2; ++k) {
         RTCHECK(rt::dzero(h->d_z[k], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
         RTCHECK(rt::dzero(h->d_v[k], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
@@ -441,6 +605,7 @@ int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_
 
 int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_t *launches) {
     if (!h || !avg_ms || reps < 1) return fail(SPOCK_ERR_BAD_ARG, "bad argument");
+    if (h->alg != SPOCK_ALG_CP) return fail(SPOCK_ERR_UNSUPPORTED, "kernel profiling is implemented for CP handles");
     // `reps` further CP iterations on the current state, launched one kernel at a time with a HIP event before
     // and after each launch on the handle's stream; per kind: 0 SUB_A, 1 CROWN, 2 SUB_B, 3 FULL.
     const size_t B = (size_t)h->batch;

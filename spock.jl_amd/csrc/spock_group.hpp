@@ -51,7 +51,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
     // ---- control: has this instance finished?  (FULL / CROWN also run the pending termination test)
     if (!(flags & F_NO_CTL)) {
-        if (MODE == MODE_FULL || MODE == MODE_CROWN || MODE == MODE_FINALIZE) {
+        if ((MODE == MODE_FULL || MODE == MODE_CROWN || MODE == MODE_FINALIZE) && !(flags & F_SP)) {
             if (ctl.pending && !ctl.done) {   // workgroup-parallel max over the per-workgroup residual maxima
                 x.each([&](int tid, TState<P> &) {
                     double mx[3] = {0., 0., 0.};
@@ -79,10 +79,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
     const double gamma = ctl.gamma, sigma = ctl.sigma;
     const MatPtr M = (MatPtr)a.mats;
-    const double *z = a.z_in + (long)inst * dm.nz;
-    const double *v = a.v_in + (long)inst * dm.nv;
-    double *zo = a.z_out + (long)inst * dm.nz;
-    double *vo = a.v_out + (long)inst * dm.nv;
+    const double *z = a.z_in + (long)inst * a.stride_z;
+    const double *v = a.v_in + (long)inst * a.stride_v;
+    double *zo = a.z_out + (long)inst * a.stride_z;
+    double *vo = a.v_out + (long)inst * a.stride_v;
     double *ex = x.lds();
 
     // ---- geometry of this group

@@ -67,14 +67,16 @@ enum KFlags : unsigned {
     F_NO_ALOCAL = 64u,   // skip phase A's node-local part (operator prox_h_conj)
     F_DBG_NO_BWD = 128u, // measurement only (spock_profile_kernels + SPOCK_AMD_DEBUG_FLAGS): skip the backward sweep
     F_DBG_NO_FWD = 256u, // measurement only: skip the forward sweep
+    F_SP = 1024u,        // SP driver: no CP termination prologue in the crown / whole-tree kernel, only the done check
     F_DBG_STAMPS = 512u, // measurement only: thread 0 of every workgroup of instance 0 writes clock stamps to KArgs::dbg
 };
 
 struct KArgs {
     Dims dm;
     const double *mats;
-    const double *z_in, *v_in;  // [batch][nz], [batch][nv]
-    double *z_out, *v_out;      // zbar, vbar
+    const double *z_in, *v_in;  // input iterate; instance b starts at z_in + b*stride_z, v_in + b*stride_v
+    double *z_out, *v_out;      // zbar, vbar (same strides)
+    long stride_z, stride_v;    // CP: nz, nv (separate arrays); SP: nz + nv for both (z|v concatenated per instance)
     double *dbuf;               // [batch][nn*nu]      S1's d_i between phase A and phase B
     double *qroot;              // [batch][nsub*nx]    S1's q at the subtree roots
     double *cbuf;               // [batch][crown non-leaf nodes][nx+nu]  node-local terms of the crown's sweep
@@ -88,6 +90,40 @@ struct KArgs {
     unsigned flags;
     int batch;
 };
+
+// ---- SP (SuperMann + Anderson) driver: plain data shared by the kernels (spock_sp.hpp) and the driver ----
+struct SpCtl {          // per instance, device memory; survives between solves where the reference's state does
+    int k;              // Anderson calls in this solve (anderson!'s `iter`), reset per solve
+    int head;           // physical column (0..2) holding the newest logical column of MP / Q
+    int accept;         // decision of the current iteration: 1 K1, 2 K2, 0 plain CP step
+    int backtrack;      // 0 or 9
+    double R[9];        // aa_R, column-major 3x3 upper triangular; persists between solves
+    double r_safe, rnorm, rtilde, rho_dot, coef;
+    double r2, r3, rho, g[3];
+};
+
+constexpr int kSpSums = 10;   // partial sums per workgroup of the flat / LOP kernels
+
+struct SpArgs {
+    Dims dm;
+    const double *mats;
+    Ctl *ctl;
+    SpCtl *sp;
+    // every vector is [batch][nr], nr = nz + nv, z part first
+    double *Z, *ZB, *ZOLD, *R, *ROLD, *DP, *W, *WB, *RW, *D;
+    double *MP, *Q;            // [batch][3][nr], circular columns
+    double *partF;             // [batch][n_partF][kSpSums] partial sums of the flat kernels
+    double *partL;             // [batch][n_partL][kSpSums] partial sums (0,1) and maxima (2,3) of the LOP kernels
+    double *hist;
+    int hist_cap;
+    int n_partF, n_partL;      // workgroups per instance of the kernels that fill partF / partL
+    int batch;
+    long nr;
+    int op;
+};
+
+enum SpOp { SP_FLAT1 = 1, SP_FLAT2, SP_FLAT3, SP_FLAT4, SP_FLAT5, SP_LOP_R, SP_LOP_RT, SP_LOP_DP,
+            SP_CTL_A, SP_CTL_B, SP_CTL_C, SP_CTL_D };
 
 enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, MODE_FINALIZE = 4 };
 
@@ -114,5 +150,8 @@ int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tre
 // Each returns a hipError_t cast to int.  `stream` is a hipStream_t.
 int launch_group(int mode, const KArgs &a, void *stream);
 bool have_static_variant(int nx, int nu, int d, int ny);
+int launch_sp(const SpArgs &a, void *stream);   // a.op selects the kernel (spock_sp.hpp)
+int sp_flat_blocks(long nr);                    // workgroups per instance of the flat kernels
+int sp_lop_blocks(const Dims &dm);              // workgroups per instance of the LOP kernels
 
 }  // namespace spock

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "spock_group.hpp"
+#include "spock_sp.hpp"
 
 namespace spock {
 
@@ -104,6 +105,151 @@ int launch_group(int mode, const KArgs &a, void *stream) {
     SPOCK_STATIC_SHAPES(X)
 #undef X
     return cm == 2 ? launch_variant<DynDims<2>>(mode, a, st) : cm == 1 ? launch_variant<DynDims<1>>(mode, a, st) : launch_variant<DynDims<0>>(mode, a, st);
+}
+
+
+// ===================================================================================================
+// SP (SuperMann + Anderson) kernels: flat vector steps, node-local L / L' application, control steps
+// ===================================================================================================
+constexpr int kFlatThreads = 256, kFlatPerThread = 4, kCtlThreads = 256;
+
+int sp_flat_blocks(long nr) {
+    long b = (nr + (long)kFlatThreads * kFlatPerThread - 1) / ((long)kFlatThreads * kFlatPerThread);
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+int sp_lop_blocks(const Dims &dm) { return dm.t0 > 0 ? dm.nsub + 1 : 1; }
+
+// deterministic workgroup reduction of K per-thread values (sum or NaN-propagating max): fixed shuffle tree
+// inside a wave, then the waves in order
+template <int K, bool MAXOP>
+__device__ __forceinline__ void block_reduce(double *v, double *lds /* [K][16] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_down(x, off, 64);
+            x = MAXOP ? spk_max_nan(x, o) : x + o;
+        }
+        if (lane == 0) lds[k * 16 + wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double x = lds[k * 16];
+            for (int w = 1; w < nw; ++w) x = MAXOP ? spk_max_nan(x, lds[k * 16 + w]) : x + lds[k * 16 + w];
+            v[k] = x;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kFlatThreads) spock_sp_flat_kernel(const SpArgs a) {
+    const int inst = blockIdx.y;
+    if (a.ctl[inst].done) return;
+    __shared__ double red[6 * 16];
+    const SpCtl c = a.sp[inst];
+    double sums[6] = {0., 0., 0., 0., 0., 0.};
+    const long stride = (long)gridDim.x * kFlatThreads;
+    for (long e = (long)blockIdx.x * kFlatThreads + threadIdx.x; e < a.nr; e += stride) sp_flat_elem(a, c, inst, e, sums);
+    if (a.op == SP_FLAT1 || a.op == SP_FLAT2) {
+        block_reduce<6, false>(sums, red);
+        if (threadIdx.x == 0) {
+            double *dst = a.partF + ((long)inst * a.n_partF + blockIdx.x) * kSpSums;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dst[k] = sums[k];
+        }
+    }
+}
+
+template <class P>
+__global__ void __launch_bounds__(512) spock_sp_lop_kernel(const SpArgs a) {
+    const int inst = blockIdx.y, g = blockIdx.x;
+    if (a.ctl[inst].done) return;
+    __shared__ double red[4 * 16];
+    const Dims &dm = a.dm;
+    const P p(dm);
+    const bool split = dm.t0 > 0, crown = split && g == dm.nsub;
+    TState<P> s;
+    init_geometry(p, dm, (int)threadIdx.x, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0,
+                  crown ? dm.t0 + 1 : (split ? dm.sub_stages : dm.N), crown, s);
+    const long o = (long)inst * a.nr;
+    const double *A = nullptr, *B = nullptr, *B2 = nullptr;
+    if (a.op == SP_LOP_R) { A = a.R + o; B = a.R + o; }
+    else if (a.op == SP_LOP_RT) { A = a.RW + o; B = a.RW + o; B2 = a.D + o; }
+    else { B = a.DP + o; }
+    double acc[4] = {0., 0., 0., 0.};
+    if (s.active) lop_local(p, dm, (MatPtr)a.mats, A, B, B2, s, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
+    double mx[2] = {acc[2], acc[3]};
+    block_reduce<2, false>(acc, red);
+    __syncthreads();
+    block_reduce<2, true>(mx, red);
+    if (threadIdx.x == 0) {
+        double *dst = a.partL + ((long)inst * a.n_partL + g) * kSpSums;
+        dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = mx[0]; dst[3] = mx[1];
+    }
+}
+
+__global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs a) {
+    const int inst = blockIdx.y;
+    Ctl &ctl = a.ctl[inst];
+    if (ctl.done) return;
+    __shared__ double red[6 * 16];
+    SpCtl &c = a.sp[inst];
+    const double *pf = a.partF + (long)inst * a.n_partF * kSpSums, *pl = a.partL + (long)inst * a.n_partL * kSpSums;
+    double f[6] = {0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
+    if (a.op == SP_CTL_A || a.op == SP_CTL_B)
+        for (int r = threadIdx.x; r < a.n_partF; r += kCtlThreads)
+            for (int k = 0; k < 6; ++k) f[k] += pf[(long)r * kSpSums + k];
+    if (a.op == SP_CTL_A || a.op == SP_CTL_C)
+        for (int r = threadIdx.x; r < a.n_partL; r += kCtlThreads) { l[0] += pl[(long)r * kSpSums]; l[1] += pl[(long)r * kSpSums + 1]; }
+    if (a.op == SP_CTL_D)
+        for (int r = threadIdx.x; r < a.n_partL; r += kCtlThreads) {
+            m[0] = spk_max_nan(m[0], pl[(long)r * kSpSums + 2]); m[1] = spk_max_nan(m[1], pl[(long)r * kSpSums + 3]);
+        }
+    block_reduce<6, false>(f, red);
+    __syncthreads();
+    block_reduce<2, false>(l, red);
+    __syncthreads();
+    block_reduce<2, true>(m, red);
+    if (threadIdx.x == 0) {
+        if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0]);
+        else if (a.op == SP_CTL_B) sp_ctl_b(c, f);
+        else if (a.op == SP_CTL_C) sp_ctl_c(c, ctl, l[0], l[1]);
+        else if (a.op == SP_CTL_D) sp_ctl_d(c, ctl, m[0], m[1], a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr, a.hist_cap);
+    }
+}
+
+template <class P>
+static int launch_lop(const SpArgs &a, hipStream_t st) {
+    const Dims &dm = a.dm;
+    const int sub_thr = group_threads(dm.d, dm.sub_stages), crown_thr = group_threads(dm.d, dm.t0 + 1);
+    const int nthr = dm.t0 > 0 ? (sub_thr > crown_thr ? sub_thr : crown_thr) : group_threads(dm.d, dm.N);
+    hipLaunchKernelGGL((spock_sp_lop_kernel<P>), dim3(sp_lop_blocks(dm), a.batch), dim3(round64(nthr)), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+int launch_sp(const SpArgs &a, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const Dims &dm = a.dm;
+    switch (a.op) {
+        case SP_FLAT1: case SP_FLAT2: case SP_FLAT3: case SP_FLAT4: case SP_FLAT5:
+            hipLaunchKernelGGL(spock_sp_flat_kernel, dim3(a.n_partF, a.batch), dim3(kFlatThreads), 0, st, a);
+            return (int)hipGetLastError();
+        case SP_CTL_A: case SP_CTL_B: case SP_CTL_C: case SP_CTL_D:
+            hipLaunchKernelGGL(spock_sp_ctl_kernel, dim3(1, a.batch), dim3(kCtlThreads), 0, st, a);
+            return (int)hipGetLastError();
+        default: break;
+    }
+    const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
+#define X(a_, b_, c_, e_)                                                          \
+    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                    \
+        return cm == 2 ? launch_lop<StaticDims<a_, b_, c_, e_, 2>>(a, st)           \
+             : cm == 1 ? launch_lop<StaticDims<a_, b_, c_, e_, 1>>(a, st) : launch_lop<StaticDims<a_, b_, c_, e_, 0>>(a, st);
+    SPOCK_STATIC_SHAPES(X)
+#undef X
+    return cm == 2 ? launch_lop<DynDims<2>>(a, st) : cm == 1 ? launch_lop<DynDims<1>>(a, st) : launch_lop<DynDims<0>>(a, st);
 }
 
 }  // namespace spock

@@ -1,0 +1,259 @@
+// spock_sp.hpp -- device pieces of the SuperMann-accelerated CP driver ("SP" = Spock):
+//   run_sp!            /root/reference/src/model_algorithms/sp.jl:358-469
+//   anderson!          /root/reference/src/model_algorithms/qnewton_directions/anderson.jl:1-123
+//   spock_dot / norm   /root/reference/src/model_dynamics/implicit_l.jl:485-557
+//
+// One SP iteration on the device (driver: spock_abi.cpp; every kernel exits at once for a finished instance):
+//   T(Z) -> ZB                                   the three CP kernels (spock_group.hpp)
+//   FLAT1   r = Z - ZB, dr = r - r_old, new Anderson columns, Gram sums      (anderson.jl:13-65)
+//   LOP     <r, P r>                                                          (sp.jl:34-51)
+//   CTL_A   rnorm, Gram-Schmidt coefficients r2, r3, shift of R              (anderson.jl:46-50,76-88)
+//   FLAT2   Q1 = dr - r2 Q2 - r3 Q3, its norm, Q'r                           (anderson.jl:88-110)
+//   CTL_B   R11, gamma = R^-1 Q'r                                            (anderson.jl:94-113)
+//   FLAT3   Q1 /= rho, d = -r - MP gamma, candidate W = Z + d                (anderson.jl:116-122, sp.jl:118-131)
+//   T(W) -> WB
+//   FLAT4   rt = W - WB                                                      (sp.jl:155-160)
+//   LOP     <rt, P rt>, <rt, P d>                                            (sp.jl:163, :420-434)
+//   CTL_C   K1 / K2 / fall-back decision, r_safe, backtrack count           (sp.jl:411-446)
+//   FLAT5   Z <- W | Z - coef rt | ZB ;  dp = Z - Z_old                      (sp.jl:166-222, :270-281)
+//   LOP     xi_1 = |L' dp_v - dp_z / gamma|_inf, xi_2 = |L dp_z - dp_v / sigma|_inf   (sp.jl:283-293)
+//   CTL_D   termination test, history, counters                             (sp.jl:295-344, :464)
+//
+// Differences from the reference that leave the iterates unchanged: the Anderson buffers are circular
+// (no column shifting), MR is not stored (it only ever feeds Q), a rejected candidate is
+// evaluated once instead of nine identical times (tau never changes: the line search result is discarded,
+// sp.jl:439; the logged backtrack count is still 9).  Differences at rounding level: parallel summation order
+// in the inner products, and the Gram-Schmidt coefficient against the third column is formed from Gram
+// sums, (<Q3,Q1> - r2 <Q3,Q2>) / |Q3|, instead of a pass over the updated column.
+#pragma once
+#include "spock_device.hpp"
+
+namespace spock {
+
+SPK_DEV int sp_col(const SpCtl &c, int logical /*0 = newest*/) { return (c.head + logical) % 3; }
+
+// ---------------------------------------------------------------------------------------------------
+// flat element-wise steps; `e` is the element index inside the instance's nr-vector, sums[] accumulates
+SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, double *sums) {
+    const long o = (long)inst * a.nr + e;
+    const long m3 = (long)inst * 3 * a.nr;
+    double *q1 = a.Q + m3 + (long)sp_col(c, 0) * a.nr, *q2 = a.Q + m3 + (long)sp_col(c, 1) * a.nr,
+           *q3 = a.Q + m3 + (long)sp_col(c, 2) * a.nr;
+    double *p1 = a.MP + m3 + (long)sp_col(c, 0) * a.nr, *p2 = a.MP + m3 + (long)sp_col(c, 1) * a.nr,
+           *p3 = a.MP + m3 + (long)sp_col(c, 2) * a.nr;
+    switch (a.op) {
+        case SP_FLAT1: {   // head already points at the slot of the new column (set by CTL_D / solve start)
+            const double z = a.Z[o], r = z - a.ZB[o];
+            const double dr = r - a.ROLD[o];
+            a.R[o] = r;
+            p1[e] = a.DP[o] - dr;                 // MP[:,1] = delta_p - delta_r   (anderson.jl:25-32)
+            q1[e] = dr;                           // Q[:,1]  = MR[:,1] = delta_r   (anderson.jl:63-65)
+            a.ROLD[o] = r;                        // update_sy! (sp.jl:232-255)
+            a.ZOLD[o] = z;
+            const double b = q2[e], cc = q3[e];
+            sums[0] += dr * dr; sums[1] += b * dr; sums[2] += cc * dr; sums[3] += b * b; sums[4] += cc * cc; sums[5] += b * cc;
+        } break;
+        case SP_FLAT2: {
+            const double v = q1[e] - c.r2 * q2[e] - c.r3 * q3[e];   // anderson.jl:88
+            q1[e] = v;
+            const double r = a.R[o];
+            sums[0] += v * v; sums[1] += v * r; sums[2] += q2[e] * r; sums[3] += q3[e] * r;
+        } break;
+        case SP_FLAT3: {
+            q1[e] = q1[e] / c.rho;                                   // anderson.jl:94-98
+            const double w = (p1[e] * c.g[0] + p2[e] * c.g[1]) + p3[e] * c.g[2];   // MP gamma (anderson.jl:116)
+            const double d = -a.R[o] - w;                            // anderson.jl:117-122
+            a.D[o] = d;
+            a.W[o] = a.Z[o] + 1. * d;                                // tau = 1 (sp.jl:118-131)
+        } break;
+        case SP_FLAT4:
+            a.RW[o] = a.W[o] - a.WB[o];                              // sp.jl:155-160
+            break;
+        case SP_FLAT5: {
+            double z = a.Z[o];
+            if (c.accept == 1) z = a.W[o];                           // K1 (sp.jl:166-191)
+            else if (c.accept == 2) z -= c.coef * a.RW[o];           // K2 (sp.jl:193-222)
+            else z = a.ZB[o];                                        // plain CP step (sp.jl:443-446)
+            a.Z[o] = z;
+            a.DP[o] = z - a.ZOLD[o];                                 // delta_z / delta_v (sp.jl:279-284)
+        } break;
+        default: break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// node-local application of L / L' to a vector pair b (and optionally b2) on the entries owned by node i:
+//   acc[0] += <a, P b>   acc[1] += <a, P b2>      P = [[I, -gamma L'], [-sigma L, I]]   (implicit_l.jl:485-516)
+//   acc[2] = max |L' b_v - b_z / gamma|           acc[3] = max |L b_z - b_v / sigma|    (sp.jl:283-293)
+template <class P>
+SPK_DEV void lop_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ A, const double *__restrict__ Bv,
+                       const double *__restrict__ B2, const TState<P> &s, double gamma, double sigma, double *acc) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
+    const int i = s.node, nxu = nx + nu, nz = dm.nz;
+    const double nig = -1. / gamma, nis = -1. / sigma;
+    const int nb = B2 ? 2 : 1;
+    for (int which = 0; which < nb; ++which) {
+        const double *__restrict__ b = which ? B2 : Bv;
+        const double *bz = b, *bv = b + nz;
+        const double *az = A, *av = A ? A + nz : nullptr;
+        double sum = 0., m1 = acc[2], m2 = acc[3];
+        const MatPtr bb = M + dm.mb;
+        // ---- z entries x_i, u_i and v entries v7, v3_c, v4_c
+        double bx[P::MAXNX], bu[P::MAXNU], ltx[P::MAXNX], ltu[P::MAXNU];
+        SPK_UNROLL for (int k = 0; k < nx; ++k) { bx[k] = bz[dm.zx + i * nx + k]; ltx[k] = bv[dm.o7 + i * nxu + k]; }
+        SPK_UNROLL for (int k = 0; k < nu; ++k) { bu[k] = bz[dm.zu + i * nu + k]; ltu[k] = bv[dm.o7 + i * nxu + nx + k]; }
+        // v7 = (x_i, u_i)
+        SPK_UNROLL for (int k = 0; k < nx; ++k) {
+            const double lb = bx[k], vb = ltx[k];
+            if (A) sum += av[dm.o7 + i * nxu + k] * (vb - sigma * lb);
+            m2 = spk_max_nan(m2, fabs(lb + nis * vb));
+        }
+        SPK_UNROLL for (int k = 0; k < nu; ++k) {
+            const double lb = bu[k], vb = ltu[k];
+            if (A) sum += av[dm.o7 + i * nxu + nx + k] * (vb - sigma * lb);
+            m2 = spk_max_nan(m2, fabs(lb + nis * vb));
+        }
+        SPK_UNROLL for (int c = 0; c < d; ++c) {
+            const int j = s.c0 + c, jn = j - 1;
+            const MatPtr SQ = M + dm.mSqQ + (P::SHARED ? 0 : jn) * nx * nx;
+            const MatPtr SR = M + dm.mSqR + (P::SHARED ? 0 : jn) * nu * nu;
+            double l3[P::MAXNX], l4[P::MAXNU];
+            sym_mv<P, false>(nx, SQ, bx, l3);                 // (L b_z) on v3_j
+            sym_mv<P, false>(nu, SR, bu, l4);                 // (L b_z) on v4_j
+            sym_mv<P, true>(nx, SQ, bv + dm.o3 + jn * nx, ltx);   // L' contribution to x_i
+            sym_mv<P, true>(nu, SR, bv + dm.o4 + jn * nu, ltu);   // L' contribution to u_i
+            SPK_UNROLL for (int k = 0; k < nx; ++k) {
+                const double vb = bv[dm.o3 + jn * nx + k];
+                if (A) sum += av[dm.o3 + jn * nx + k] * (vb - sigma * l3[k]);
+                m2 = spk_max_nan(m2, fabs(l3[k] + nis * vb));
+            }
+            SPK_UNROLL for (int k = 0; k < nu; ++k) {
+                const double vb = bv[dm.o4 + jn * nu + k];
+                if (A) sum += av[dm.o4 + jn * nu + k] * (vb - sigma * l4[k]);
+                m2 = spk_max_nan(m2, fabs(l4[k] + nis * vb));
+            }
+            // tau_j <-> v5_j, v6_j
+            const double bt = bz[dm.zt + jn], b5 = bv[dm.o5 + jn], b6 = bv[dm.o6 + jn];
+            const double lt = 0.5 * b5 + 0.5 * b6, l56 = 0.5 * bt;
+            if (A) sum += az[dm.zt + jn] * (bt - gamma * lt) + av[dm.o5 + jn] * (b5 - sigma * l56) + av[dm.o6 + jn] * (b6 - sigma * l56);
+            m1 = spk_max_nan(m1, fabs(lt + nig * bt));
+            m2 = spk_max_nan(m2, fabs(l56 + nis * b5));
+            m2 = spk_max_nan(m2, fabs(l56 + nis * b6));
+            if (s.kids_leaf) {
+                const int li = j - dm.nn;
+                const MatPtr SN = M + dm.mSqQN + (P::SHARED ? 0 : li) * nx * nx;
+                double bxl[P::MAXNX], l11[P::MAXNX], lt11[P::MAXNX];
+                SPK_UNROLL for (int k = 0; k < nx; ++k) bxl[k] = bz[dm.zx + j * nx + k];
+                sym_mv<P, false>(nx, SN, bxl, l11);
+                sym_mv<P, false>(nx, SN, bv + dm.o11 + li * nx, lt11);
+                SPK_UNROLL for (int k = 0; k < nx; ++k) {
+                    const double v11 = bv[dm.o11 + li * nx + k], v14 = bv[dm.o14 + li * nx + k];
+                    const double ltxl = v14 + lt11[k];
+                    if (A) sum += az[dm.zx + j * nx + k] * (bxl[k] - gamma * ltxl) + av[dm.o11 + li * nx + k] * (v11 - sigma * l11[k])
+                                  + av[dm.o14 + li * nx + k] * (v14 - sigma * bxl[k]);
+                    m1 = spk_max_nan(m1, fabs(ltxl + nig * bxl[k]));
+                    m2 = spk_max_nan(m2, fabs(l11[k] + nis * v11));
+                    m2 = spk_max_nan(m2, fabs(bxl[k] + nis * v14));
+                }
+                const double bs = bz[dm.zs + j], b12 = bv[dm.o12 + li], b13 = bv[dm.o13 + li];
+                const double lts = 0.5 * b12 + 0.5 * b13, l1213 = 0.5 * bs;
+                if (A) sum += az[dm.zs + j] * (bs - gamma * lts) + av[dm.o12 + li] * (b12 - sigma * l1213) + av[dm.o13 + li] * (b13 - sigma * l1213);
+                m1 = spk_max_nan(m1, fabs(lts + nig * bs));
+                m2 = spk_max_nan(m2, fabs(l1213 + nis * b12));
+                m2 = spk_max_nan(m2, fabs(l1213 + nis * b13));
+            }
+        }
+        SPK_UNROLL for (int k = 0; k < nx; ++k) {
+            if (A) sum += az[dm.zx + i * nx + k] * (bx[k] - gamma * ltx[k]);
+            m1 = spk_max_nan(m1, fabs(ltx[k] + nig * bx[k]));
+        }
+        SPK_UNROLL for (int k = 0; k < nu; ++k) {
+            if (A) sum += az[dm.zu + i * nu + k] * (bu[k] - gamma * ltu[k]);
+            m1 = spk_max_nan(m1, fabs(ltu[k] + nig * bu[k]));
+        }
+        // ---- y_i, s_i <-> v1_i, v2_i
+        const double bs = bz[dm.zs + i], b2v = bv[dm.o2 + i];
+        double bdot = 0.;
+        SPK_UNROLL for (int k = 0; k < ny; ++k) {
+            const double by = bz[dm.zy + i * ny + k], b1 = bv[i * ny + k];
+            bdot += bb[k] * by;
+            const double lty = b1 - bb[k] * b2v;                     // (L' b_v) on y
+            if (A) sum += az[dm.zy + i * ny + k] * (by - gamma * lty) + av[i * ny + k] * (b1 - sigma * by);
+            m1 = spk_max_nan(m1, fabs(lty + nig * by));
+            m2 = spk_max_nan(m2, fabs(by + nis * b1));
+        }
+        const double l2 = bs - bdot;                                  // (L b_z) on v2
+        if (A) sum += az[dm.zs + i] * (bs - gamma * b2v) + av[dm.o2 + i] * (b2v - sigma * l2);
+        m1 = spk_max_nan(m1, fabs(b2v + nig * bs));
+        m2 = spk_max_nan(m2, fabs(l2 + nis * b2v));
+        acc[which] += sum;
+        if (which == 0) { acc[2] = m1; acc[3] = m2; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// control steps, ONE thread per instance; `sums` are the reduced partial sums of the preceding kernel(s)
+SPK_DEV void sp_ctl_a(SpCtl &c, const double *gram, double pr) {
+    c.rnorm = sqrt(pr);                                              // sp.jl:395, implicit_l.jl:545-557
+    c.k += 1;                                                        // generate_qnewton_direction! (models/spock.jl:212-224)
+    // shift R diagonally (anderson.jl:46-50); reads below the diagonal of the UpperTriangular give 0
+    double *R = c.R;
+    for (int j = 1; j >= 0; --j)
+        for (int i = 1; i >= 0; --i) R[(i + 1) + (j + 1) * 3] = (i <= j) ? R[i + j * 3] : 0.;
+    c.r2 = 0.; c.r3 = 0.;
+    if (c.k >= 2) { c.r2 = gram[1] / sqrt(gram[3]); R[0 + 1 * 3] = c.r2; }                       // anderson.jl:77-88, j = 2
+    if (c.k >= 3) { c.r3 = (gram[2] - c.r2 * gram[5]) / sqrt(gram[4]); R[0 + 2 * 3] = c.r3; }    // j = 3
+}
+SPK_DEV void sp_ctl_b(SpCtl &c, const double *s4) {
+    c.rho = sqrt(s4[0]);                                             // anderson.jl:70-75 / :93-99
+    c.R[0] = c.rho;
+    double g[3] = {s4[1] / c.rho, s4[2], s4[3]};                     // gamma = Q' r with Q1 normalised (anderson.jl:110)
+    const double *R = c.R;
+    for (int j = 2; j >= 0; --j) {                                   // ldiv!(UpperTriangular(R), gamma) (anderson.jl:113)
+        g[j] = g[j] / R[j + j * 3];
+        for (int i = j - 1; i >= 0; --i) g[i] -= g[j] * R[i + j * 3];
+    }
+    c.g[0] = g[0]; c.g[1] = g[1]; c.g[2] = g[2];
+}
+SPK_DEV void sp_ctl_c(SpCtl &c, const Ctl &ctl, double s_rt, double s_rtd) {
+    const double c1 = 0.99, q = 0.99, sigma_k2 = 0.1, lambda_sp = 1.;   // run_sp! keyword defaults (sp.jl:364-372)
+    c.rtilde = sqrt(s_rt);
+    c.accept = 0; c.backtrack = 9; c.coef = 0.;                      // rejected candidate: 9 identical re-evaluations, then CP step
+    if (c.rnorm <= c.r_safe && c.rtilde <= c1 * c.rnorm) {           // K1 (sp.jl:166-174)
+        c.accept = 1; c.backtrack = 0;
+        c.r_safe = c.rtilde + pow(q, (double)ctl.iter);              // sp.jl:187
+        return;
+    }
+    const double rho = s_rt - 1. * s_rtd;                            // <rt, P (rt - tau d)>, tau = 1 (sp.jl:420-434)
+    c.rho_dot = rho;
+    if (rho >= sigma_k2 * c.rnorm * c.rtilde) {                      // K2 (sp.jl:193-201)
+        c.accept = 2; c.backtrack = 0;
+        c.coef = lambda_sp * (rho / (c.rtilde * c.rtilde));          // sp.jl:211-218
+    }
+}
+SPK_DEV void sp_ctl_d(SpCtl &c, Ctl &ctl, double x1, double x2, double *hist, int hist_cap) {
+    c.head = (c.head + 2) % 3;     // the next anderson! call writes its new column into the slot of the oldest one
+    const bool log = (ctl.log_mode == 2);
+    const double xi = log ? (x1 > x2 ? x1 : x2) : NAN;               // sp.jl:308
+    ctl.xi1 = x1; ctl.xi2 = x2; ctl.xi = xi;
+    if (hist && ctl.evals < hist_cap) {
+        double *h = hist + (long)ctl.evals * kHistStride;
+        h[0] = xi; h[1] = x1; h[2] = x2; h[3] = (double)c.backtrack;
+    }
+    ctl.evals += 1;
+    bool term;
+    if (log) term = (xi <= ctl.tol);
+    else {
+        const double t1 = ctl.tol * ctl.res0[0] > ctl.tol ? ctl.tol * ctl.res0[0] : ctl.tol;
+        const double t2 = ctl.tol * ctl.res0[1] > ctl.tol ? ctl.tol * ctl.res0[1] : ctl.tol;
+        term = (x1 <= t1 && x2 <= t2);
+    }
+    if (ctl.res0[0] == -INFINITY) ctl.res0[0] = x1;
+    if (ctl.res0[1] == -INFINITY) ctl.res0[1] = x2;
+    if (x1 != x1 || x2 != x2) { ctl.done = 1; ctl.status = 2; return; }   // the reference would spin to MAX_ITER on NaNs
+    if (term) { ctl.done = 1; ctl.status = 0; return; }
+    ctl.iter += 1;
+    if (ctl.iter >= ctl.max_iter) { ctl.done = 1; ctl.status = 1; return; }
+}
+
+}  // namespace spock

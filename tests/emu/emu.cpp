@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../spock.jl_amd/csrc/spock_group.hpp"
+#include "../../spock.jl_amd/csrc/spock_sp.hpp"
 #include "../../spock.jl_amd/csrc/spock_rt.hpp"
 
 namespace spock {
@@ -104,6 +105,90 @@ int launch_group(int mode, const KArgs &a, void *) {
 #undef X
     }
     return cm == 2 ? launch_variant<DynDims<2>>(mode, a) : cm == 1 ? launch_variant<DynDims<1>>(mode, a) : launch_variant<DynDims<0>>(mode, a);
+}
+
+// ---- SP kernels, emulated ---------------------------------------------------------------------------
+int sp_flat_blocks(long nr) {
+    long b = (nr + 1023) / 1024;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+int sp_lop_blocks(const Dims &dm) { return dm.t0 > 0 ? dm.nsub + 1 : 1; }
+
+template <class P>
+static int emu_lop(const SpArgs &a) {
+    const Dims &dm = a.dm;
+    const P p(dm);
+    const int sub_thr = group_threads(dm.d, dm.sub_stages), crown_thr = group_threads(dm.d, dm.t0 + 1);
+    const int nthr = round64(dm.t0 > 0 ? (sub_thr > crown_thr ? sub_thr : crown_thr) : group_threads(dm.d, dm.N));
+    for (int inst = 0; inst < a.batch; ++inst) {
+        if (a.ctl[inst].done) continue;
+        for (int g = 0; g < sp_lop_blocks(dm); ++g) {
+            const bool split = dm.t0 > 0, crown = split && g == dm.nsub;
+            const long o = (long)inst * a.nr;
+            const double *A = nullptr, *B = nullptr, *B2 = nullptr;
+            if (a.op == SP_LOP_R) { A = a.R + o; B = a.R + o; }
+            else if (a.op == SP_LOP_RT) { A = a.RW + o; B = a.RW + o; B2 = a.D + o; }
+            else { B = a.DP + o; }
+            double tot[4] = {0., 0., 0., 0.};
+            for (int tid = 0; tid < nthr; ++tid) {
+                TState<P> s;
+                init_geometry(p, dm, tid, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0,
+                              crown ? dm.t0 + 1 : (split ? dm.sub_stages : dm.N), crown, s);
+                double acc[4] = {0., 0., 0., 0.};
+                if (s.active) lop_local(p, dm, (MatPtr)a.mats, A, B, B2, s, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
+                tot[0] += acc[0]; tot[1] += acc[1];
+                tot[2] = spk_max_nan(tot[2], acc[2]); tot[3] = spk_max_nan(tot[3], acc[3]);
+            }
+            double *dst = a.partL + ((long)inst * a.n_partL + g) * kSpSums;
+            for (int k = 0; k < 4; ++k) dst[k] = tot[k];
+        }
+    }
+    return 0;
+}
+
+int launch_sp(const SpArgs &a, void *) {
+    const Dims &dm = a.dm;
+    if (a.op >= SP_FLAT1 && a.op <= SP_FLAT5) {
+        for (int inst = 0; inst < a.batch; ++inst) {
+            if (a.ctl[inst].done) continue;
+            const SpCtl c = a.sp[inst];
+            for (int blk = 0; blk < a.n_partF; ++blk) {
+                double sums[6] = {0., 0., 0., 0., 0., 0.};
+                for (long e = blk; e < a.nr; e += a.n_partF) sp_flat_elem(a, c, inst, e, sums);
+                double *dst = a.partF + ((long)inst * a.n_partF + blk) * kSpSums;
+                if (a.op == SP_FLAT1 || a.op == SP_FLAT2) for (int k = 0; k < 6; ++k) dst[k] = sums[k];
+            }
+        }
+        return 0;
+    }
+    if (a.op >= SP_CTL_A) {
+        for (int inst = 0; inst < a.batch; ++inst) {
+            Ctl &ctl = a.ctl[inst];
+            if (ctl.done) continue;
+            SpCtl &c = a.sp[inst];
+            const double *pf = a.partF + (long)inst * a.n_partF * kSpSums, *pl = a.partL + (long)inst * a.n_partL * kSpSums;
+            double f[6] = {0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
+            for (int r = 0; r < a.n_partF; ++r) for (int k = 0; k < 6; ++k) f[k] += pf[(long)r * kSpSums + k];
+            for (int r = 0; r < a.n_partL; ++r) {
+                l[0] += pl[(long)r * kSpSums]; l[1] += pl[(long)r * kSpSums + 1];
+                m[0] = spk_max_nan(m[0], pl[(long)r * kSpSums + 2]); m[1] = spk_max_nan(m[1], pl[(long)r * kSpSums + 3]);
+            }
+            if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0]);
+            else if (a.op == SP_CTL_B) sp_ctl_b(c, f);
+            else if (a.op == SP_CTL_C) sp_ctl_c(c, ctl, l[0], l[1]);
+            else sp_ctl_d(c, ctl, m[0], m[1], a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr, a.hist_cap);
+        }
+        return 0;
+    }
+    const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
+    if (!env_on("SPOCK_EMU_FORCE_DYN")) {
+#define X(a_, b_, c_, e_)                                                  \
+    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)            \
+        return cm == 2 ? emu_lop<StaticDims<a_, b_, c_, e_, 2>>(a) : cm == 1 ? emu_lop<StaticDims<a_, b_, c_, e_, 1>>(a) : emu_lop<StaticDims<a_, b_, c_, e_, 0>>(a);
+        SPOCK_STATIC_SHAPES(X)
+#undef X
+    }
+    return cm == 2 ? emu_lop<DynDims<2>>(a) : cm == 1 ? emu_lop<DynDims<1>>(a) : emu_lop<DynDims<0>>(a);
 }
 
 // ---- spock_rt.hpp on host memory ---------------------------------------------------------------------

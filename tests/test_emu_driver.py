@@ -133,11 +133,68 @@ def test_emulated_build_products_match_oracle(S, O, emu):
         m.close()
 
 
+def _sp_compare(S, O, m, flat, x0, tol, vb, n_tight=30):
+    o = O.Oracle(flat, O.SP)
+    r = S.solve_model(m, x0, tol=tol, verbose=vb)
+    ro = o.solve(x0, tol=tol, verbose=int(vb), history=3000)
+    h = m.history()
+    n = min(n_tight, len(h["xi1"]), len(ro["hist_xi1"]))
+    # SP trajectories are chaotically sensitive to rounding beyond ~50 iterations: the first
+    # iterations must agree tightly, afterwards only the qualitative behaviour is comparable
+    assert np.max(np.abs(h["xi1"][:n] - ro["hist_xi1"][:n]) / ro["hist_xi1"][:n]) <= 1e-8
+    assert np.max(np.abs(h["xi2"][:n] - ro["hist_xi2"][:n]) / ro["hist_xi2"][:n]) <= 1e-8
+    assert np.array_equal(h["backtrack"][:n], ro["hist_backtrack"][:n])
+    assert set(h["backtrack"].tolist()) <= {0, 9}
+    assert r["status"] == 0 and ro["status"] == 0
+    return r, ro, o
+
+
+@pytest.mark.parametrize("name,tol", [("car", 1e-3), ("sh7", 1e-3), ("sh7_split3", 1e-3), ("d3_static", 1e-3)])
+def test_emulated_sp_driver(S, O, emu, name, tol):
+    """SuperMann + Anderson on the kernel code path (emulated) against the oracle's bug-compatible run_sp!."""
+    specs = S.get_car_fixture(3.7) if name == "car" else _specs(S, name)     # main_profiling.jl:20-28 scales the costs for SP
+    flat = S.flatten_problem(*specs)
+    kw = dict(CASES[name][1])
+    L = None if name != "d3_static" else 1.05 * S.L_norm_sq(specs[0], specs[1], specs[3])   # 3.28 is invalid for d = 3
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, graph_iters=-2, L_norm=L, **kw)
+    x0 = np.full(flat.nx, 0.1)
+    if L is not None:
+        o = O.Oracle(flat, O.SP); o.L_norm = L
+        r = S.solve_model(m, x0, tol=tol); ro = o.solve(x0, tol=tol, history=3000)
+        h = m.history(); n = min(30, len(h["xi1"]), len(ro["hist_xi1"]))
+        assert np.max(np.abs(h["xi1"][:n] - ro["hist_xi1"][:n]) / ro["hist_xi1"][:n]) <= 1e-8
+        assert r["status"] == 0
+    else:
+        r, ro, o = _sp_compare(S, O, m, flat, x0, tol, S.SILENT)
+        if name == "car":
+            assert r["iterations"] == ro["iterations"]
+        # warm start keeps the Anderson memory (SURVEY.md appendix C-7)
+        r2 = S.solve_model(m, x0 * 1.05, tol=tol); ro2 = o.solve(x0 * 1.05, tol=tol)
+        assert r2["status"] == 0 and abs(r2["iterations"] - ro2["iterations"]) <= max(10, ro2["iterations"])
+    m.close()
+
+
+def test_emulated_sp_known_answer_trace(S, O, emu, kat_sp):
+    """examples/server_heat/residuals.jl, SP branch (residuals.tikz:3195-3765): first value to 1 ulp-level, first 40
+    iterations to 1e-6 (the tolerance north_star states), backtrack counts identical there, converges."""
+    specs = S.get_server_heat_specs(7, 5, 2)
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu)
+    r = S.solve_model(m, np.full(5, 0.1), tol=1e-5, verbose=S.LOG)
+    h = m.history()
+    assert abs(h["xi"][0] - kat_sp[0, 0]) <= 1e-14
+    assert np.max(np.abs(h["xi"][:40] - kat_sp[:40, 0]) / kat_sp[:40, 0]) <= 1e-6
+    assert np.array_equal(h["backtrack"][:40], kat_sp[:40, 1].astype(int))
+    assert r["status"] == 0 and h["xi"][-1] <= 1e-5 and r["iterations"] < 1000
+    # converged solution: SP and CP agree within the solve tolerance
+    mc = S.build_model(*specs, S.SolverOptions(S.CP, None), lib_path=emu)
+    S.solve_model(mc, np.full(5, 0.1), tol=1e-5, verbose=S.LOG)
+    sl = S.flatten_problem(*specs).z_slices()
+    assert abs(m.solver_state.z[sl["s"]][0] - mc.solver_state.z[sl["s"]][0]) <= 2e-3 * abs(mc.solver_state.z[sl["s"]][0])
+    m.close(); mc.close()
+
+
 def test_unsupported_inputs(S, emu):
     tree, cost, dyn, rms, con = S.get_server_heat_specs(4, 3, 2)
-    with pytest.raises(S.SpockError) as e:
-        S.build_model(tree, cost, dyn, rms, con, S.SolverOptions(S.SP, None), lib_path=emu)
-    assert e.value.code == 2
     bad = S.generate_scenario_tree_uniform_branching_factor_v2(4, 2, 3, 3)
     bad.anc = bad.anc.copy(); bad.anc[5] = 1
     with pytest.raises(S.SpockError):

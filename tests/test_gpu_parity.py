@@ -120,6 +120,54 @@ def test_known_answer_trace_cp(S, kat_cp):
         m.close()
 
 
+def test_known_answer_trace_sp(S, O, kat_sp):
+    """SP branch of residuals.jl on the GPU (residuals.tikz:3195-3765).  The SP trajectory is chaotically sensitive to
+    rounding beyond ~50 iterations, so: first 40 iterations within 1e-6 of the reference (north_star's
+    tolerance), identical backtrack counts there, counts in {0, 9} throughout, convergence below tol."""
+    specs = S.get_server_heat_specs(7, 5, 2)
+    for kw in ({}, {"split_stage": 3}):
+        m = S.build_model(*specs, S.SolverOptions(S.SP, None), **kw)
+        r = S.solve_model(m, np.full(5, 0.1), tol=1e-5, verbose=S.LOG)
+        h = m.history()
+        assert abs(h["xi"][0] - kat_sp[0, 0]) <= 1e-14
+        assert np.max(np.abs(h["xi"][:40] - kat_sp[:40, 0]) / kat_sp[:40, 0]) <= 1e-6
+        assert np.array_equal(h["backtrack"][:40], kat_sp[:40, 1].astype(int))
+        assert set(h["backtrack"].tolist()) <= {0, 9}
+        assert r["status"] == 0 and h["xi"][-1] <= 1e-5 and r["iterations"] < 1000
+        m.close()
+
+
+@pytest.mark.parametrize("name,scale", [("car", 3.7), ("sh7", None), ("sh8_split4", None)])
+def test_sp_solve_matches_oracle(S, O, name, scale):
+    """SuperMann + Anderson on the GPU against the oracle's bug-compatible run_sp!: first 30 iterations to 1e-8
+    (residuals and backtrack counts), convergence, warm start, and agreement with CP at the solution."""
+    specs = S.get_car_fixture(scale) if name == "car" else S.get_server_heat_specs(7 if name == "sh7" else 8, 5, 2)
+    kw = {"split_stage": 4} if name == "sh8_split4" else {}
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), **kw)
+    o = O.Oracle(flat, O.SP)
+    x0 = np.full(flat.nx, 0.1)
+    r = S.solve_model(m, x0, tol=1e-3)
+    ro = o.solve(x0, tol=1e-3, history=3000)
+    h = m.history()
+    n = min(30, len(h["xi1"]), len(ro["hist_xi1"]))
+    assert np.max(np.abs(h["xi1"][:n] - ro["hist_xi1"][:n]) / ro["hist_xi1"][:n]) <= 1e-8
+    assert np.max(np.abs(h["xi2"][:n] - ro["hist_xi2"][:n]) / ro["hist_xi2"][:n]) <= 1e-8
+    assert np.array_equal(h["backtrack"][:n], ro["hist_backtrack"][:n])
+    assert r["status"] == 0 and ro["status"] == 0
+    if name == "car":
+        assert r["iterations"] == ro["iterations"]
+    r2 = S.solve_model(m, x0 * 1.05, tol=1e-3)          # warm start: Anderson memory and iterate persist
+    assert r2["status"] == 0 and r2["iterations"] <= r["iterations"] + 20
+    mc = S.build_model(*specs, S.SolverOptions(S.CP, None), L_norm=3.28, **kw)
+    S.solve_model(mc, x0 * 1.05, tol=1e-6, verbose=S.LOG)
+    r3 = S.solve_model(m, x0 * 1.05, tol=1e-6, verbose=S.LOG)
+    assert r3["status"] == 0
+    s_sp = m.solver_state.z[flat.z_slices()["s"]][0]; s_cp = mc.solver_state.z[flat.z_slices()["s"]][0]
+    assert abs(s_sp - s_cp) <= 1e-3 * max(1e-3, abs(s_cp))
+    m.close(); mc.close()
+
+
 def test_reference_solution_properties(S, models):
     """test/model_dynamics/implicit_L.jl:59-77 on the GPU iterate of the reference's own fixture."""
     m, o, flat = models["car_N3"]
