@@ -170,7 +170,7 @@ def test_emulated_sp_driver(S, O, emu, name, tol):
             assert r["iterations"] == ro["iterations"]
         # warm start keeps the Anderson memory
         r2 = S.solve_model(m, x0 * 1.05, tol=tol); ro2 = o.solve(x0 * 1.05, tol=tol)
-        assert r2["status"] == 0 and abs(r2["iterations"] - ro2["iterations"]) <= max(10, ro2["iterations"])
+        assert r2["status"] == 0 and ro2["status"] == 0 and r2["iterations"] < r["iterations"]   # far fewer than cold
     m.close()
 
 
