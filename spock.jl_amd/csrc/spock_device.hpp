@@ -243,8 +243,10 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
 //   ex    : LDS exchange buffer, [group non-leaf local index][nx]
 //   qg    : global q of the group leaves when they are subtree roots (crown), else nullptr
 //   q_out : where the group root's q goes (subtree -> global), or nullptr
-template <class P>
-SPK_DEV void bwd_node(const P &p, const Dims &dm, MatPtr M, int t, int tau, double *ex,
+//   SW    : the sweep block of stage t ([W | V | ABK | K], spock_host.cpp) -- in LDS (const double *) or in the
+//           constant-address-space pool (MatPtr)
+template <class P, class MPT>
+SPK_DEV void bwd_node(const P &p, const Dims &dm, MPT SW, int tau, double *ex,
                       const double *qg, double *q_out, TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
     double qi[P::MAXNX], di[P::MAXNU];
@@ -255,8 +257,8 @@ SPK_DEV void bwd_node(const P &p, const Dims &dm, MatPtr M, int t, int tau, doub
         if (s.kids_leaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[k] = -s.xl[c][k]; }   // q_leaf = -xbar_leaf (:578-582)
         else if (s.kids_gleaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[k] = qg[(s.pos * d + c) * nx + k]; }
         else { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[k] = ex[(tau * d + 1 + c) * nx + k]; }
-        const MatPtr W = M + dm.mW + (t * d + c) * nx * nx;
-        const MatPtr V = M + dm.mV + (t * d + c) * nu * nx;
+        const MPT W = SW + dm.sw_oW + c * nx * nx;
+        const MPT V = SW + dm.sw_oV + c * nu * nx;
         SPK_UNROLL for (int r = 0; r < nx; ++r) {
             double a = 0.;
             SPK_UNROLL for (int k = 0; k < nx; ++k) a += W[r + k * nx] * qc[k];
@@ -276,16 +278,16 @@ SPK_DEV void bwd_node(const P &p, const Dims &dm, MatPtr M, int t, int tau, doub
 // one level of the forward roll-out (implicit_l.jl:667-681).  xroot: x of the group root (x0 or the
 // value the crown stored).  Nothing is stored to global memory here: a store in front of the level's
 // barrier would make every level wait for its write acknowledgement; fwd_store() runs after the sweep.
-template <class P>
-SPK_DEV void fwd_node(const P &p, const Dims &dm, MatPtr M, int t, int tau, double *ex,
+template <class P, class MPT>
+SPK_DEV void fwd_node(const P &p, const Dims &dm, MPT SW, MPT Bm, int tau, double *ex,
                       const double *xroot, TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
     double xi[P::MAXNX];
     if (s.lvl == 0) { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = xroot[k]; }
     else { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = ex[tau * nx + k]; }
     SPK_UNROLL for (int c = 0; c < d; ++c) {
-        const MatPtr Bw = M + dm.mB + slot_event(c, d) * nx * nu;
-        const MatPtr Ab = M + dm.mABK + ((t + 1) * d + c) * nx * nx;
+        const MPT Bw = Bm + slot_event(c, d) * nx * nu;
+        const MPT Ab = SW + dm.sw_oABK + c * nx * nx;
         SPK_UNROLL for (int r = 0; r < nx; ++r) {
             double a = 0., b2 = 0.;
             SPK_UNROLL for (int k = 0; k < nx; ++k) a += Ab[r + k * nx] * xi[k];
@@ -295,7 +297,7 @@ SPK_DEV void fwd_node(const P &p, const Dims &dm, MatPtr M, int t, int tau, doub
             else ex[(tau * d + 1 + c) * nx + r] = xc;
         }
     }
-    const MatPtr Kt = M + dm.mK + t * nu * nx;
+    const MPT Kt = SW + dm.sw_oK;
     SPK_UNROLL for (int r = 0; r < nu; ++r) {
         double a = 0.;
         SPK_UNROLL for (int k = 0; k < nx; ++k) a += Kt[r + k * nu] * xi[k];
@@ -313,6 +315,65 @@ SPK_DEV void fwd_store(const P &p, const Dims &dm, double *__restrict__ zo, cons
     if (s.kids_gleaf) {
         SPK_UNROLL for (int c = 0; c < d; ++c) {
             SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + (s.c0 + c) * nx + k] = s.xl[c][k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TEAM sweeps: T lanes per node, lane r owns row r of every mat-vec; all sweep vectors live in LDS:
+//   XQ [group non-leaf][nx]  c_i -> q_i (backward, in place) -> x_i (forward)
+//   ED [group non-leaf][nu]  e_i -> d_i (backward, in place)
+//   UL [group non-leaf][nu]  u_i (forward)
+//   XL [group leaves][nx]    q of the group leaves (backward input) -> x of the group leaves (forward output)
+// A tree level with cnt nodes is cnt*T work items strided over the workgroup, so the per-level critical path
+// is ~2 d nx FMAs per lane instead of ~2 d nx (nx + nu) for a single lane, and narrow levels no longer run
+// with 63 of 64 lanes masked.  Matrices come from the LDS-staged sweep block or from the pool (MPT).
+struct TeamLds { double *XQ, *ED, *UL, *XL; };
+
+template <class P, class MPT>
+SPK_DEV void bwd_level_team(const P &p, const Dims &dm, MPT SW, int lvl_first, int cnt, bool kids_gleaf, int T,
+                            int tid, int nthreads, const TeamLds &L) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d();
+    for (int w = tid; w < cnt * T; w += nthreads) {
+        const int pos = w / T, r = w - pos * T, li = lvl_first + pos;   // local index of the node
+        if (r >= nx && r >= nu) continue;
+        double q = (r < nx) ? L.XQ[li * nx + r] : 0., dd = (r < nu) ? L.ED[li * nu + r] : 0.;
+        for (int c = 0; c < d; ++c) {
+            const double *qc = kids_gleaf ? L.XL + (pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
+            const MPT W = SW + dm.sw_oW + c * nx * nx;
+            const MPT V = SW + dm.sw_oV + c * nu * nx;
+            if (r < nx) { SPK_UNROLL for (int k = 0; k < nx; ++k) q += W[r + k * nx] * qc[k]; }
+            if (r < nu) { SPK_UNROLL for (int k = 0; k < nx; ++k) dd -= V[r + k * nu] * qc[k]; }
+        }
+        if (r < nx) L.XQ[li * nx + r] = q;
+        if (r < nu) L.ED[li * nu + r] = dd;
+    }
+}
+
+template <class P, class MPT>
+SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_first, int cnt, bool kids_gleaf, int T,
+                            int tid, int nthreads, const TeamLds &L) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d();
+    for (int w = tid; w < cnt * T; w += nthreads) {
+        const int pos = w / T, r = w - pos * T, li = lvl_first + pos;
+        if (r >= nx && r >= nu) continue;
+        const double *xi = L.XQ + li * nx, *di = L.ED + li * nu;
+        if (r < nx) {
+            for (int c = 0; c < d; ++c) {
+                const MPT Bw = Bm + slot_event(c, d) * nx * nu;
+                const MPT Ab = SW + dm.sw_oABK + c * nx * nx;
+                double a = 0., b2 = 0.;
+                SPK_UNROLL for (int k = 0; k < nx; ++k) a += Ab[r + k * nx] * xi[k];
+                SPK_UNROLL for (int k = 0; k < nu; ++k) b2 += Bw[r + k * nx] * di[k];
+                double *dst = kids_gleaf ? L.XL + (pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
+                dst[r] = a + b2;
+            }
+        }
+        if (r < nu) {
+            const MPT Kt = SW + dm.sw_oK;
+            double a = 0.;
+            SPK_UNROLL for (int k = 0; k < nx; ++k) a += Kt[r + k * nu] * xi[k];
+            L.UL[li * nu + r] = a + di[r];
         }
     }
 }

@@ -3,7 +3,7 @@
 // per non-leaf node.  The orchestration is written once against an execution policy X:
 //   X::each(f)      run f(tid, state) for every thread of the workgroup
 //   X::barrier()    workgroup barrier (also orders the group's global-memory accesses)
-//   X::lds()        the q / x exchange buffer of the S1 sweeps
+//   X::lds()        the q / x exchange buffer of the S1 sweeps;  X::lds_mats() the staged sweep matrices
 //   X::flag()       one int shared by the workgroup
 //   X::stash3 / reduce3 / red3(k)   NaN-propagating max over the workgroup of three per-thread values;
 //                   after reduce3() (which ends in a barrier) every thread can read the results
@@ -63,9 +63,11 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 x.reduce3();
             }
             x.each([&](int tid, TState<P> &) {
-                if (tid == 0) {
+                if (tid == 0) {   // work on a register copy: one load and one store of the block instead of a dependent chain
                     double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
-                    x.flag() = ctl_prologue(ctl, x.red3(0), x.red3(1), x.red3(2), hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
+                    Ctl c = ctl;
+                    x.flag() = ctl_prologue(c, x.red3(0), x.red3(1), x.red3(2), hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
+                    ctl = c;
                 }
             });
             x.barrier();
@@ -97,15 +99,49 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     double *cb = a.cbuf ? a.cbuf + (long)inst * group_threads_dev(p.d(), dm.t0 + 1) * nxu : nullptr;
     x.each([&](int tid, TState<P> &s) { init_geometry(p, dm, tid, root_stage, root_pos, stages, crown, s); });
 
+    // ---- stage the sweep matrices of this group's stages (and B) in LDS: one coalesced copy instead of a
+    //      dependent matrix fetch in front of every tree level (measured 0.65 / 1.25 us per level without it)
+    const bool sweeping = !(flags & F_NO_SWEEP) && !crown_blk;
+    const bool lds_mats = a.lds_mats && sweeping;
+    double *lm = x.lds_mats();
+    const int n_sw = (stages - 1) * dm.sw_stride, n_b = p.d() * p.nx() * p.nu();
+    if (lds_mats) {
+        const double *src = a.mats + dm.mSweep + (long)root_stage * dm.sw_stride;
+        const double *srcB = a.mats + dm.mB;
+        x.each([&](int tid, TState<P> &) {
+            for (int k = tid; k < n_sw; k += x.nthreads()) lm[k] = src[k];
+            for (int k = tid; k < n_b; k += x.nthreads()) lm[n_sw + k] = srcB[k];
+        });
+        x.barrier();
+    }
+
+    // ---- team sweeps: carve the LDS vectors (spock_device.hpp: TeamLds)
+    const int team = sweeping ? a.team : 0;
+    const int nl_grp = group_threads_dev(p.d(), stages);          // non-leaf nodes of this group
+    int ngl_grp = 1;                                               // leaves of this group
+    for (int k = 0; k < stages - 1; ++k) ngl_grp *= p.d();
+    TeamLds tl;
+    tl.XQ = ex; tl.ED = tl.XQ + nl_grp * p.nx(); tl.UL = tl.ED + nl_grp * p.nu(); tl.XL = tl.UL + nl_grp * p.nu();
+
     // ---- phase A (node-local)
     if ((MODE == MODE_FULL || MODE == MODE_SUB_A) && !(flags & F_NO_ALOCAL)) {
         x.each([&](int, TState<P> &s) { if (s.active) a_local(p, dm, M, z, v, zo, s, gamma, flags); });
+        if (team && !crown_blk) {   // hand c_i, e_i and the leaves' q = -xbar over to the lane teams
+            x.each([&](int tid, TState<P> &s) {
+                if (!s.active) return;
+                for (int k = 0; k < p.nx(); ++k) tl.XQ[tid * p.nx() + k] = s.xb[k];
+                for (int k = 0; k < p.nu(); ++k) tl.ED[tid * p.nu() + k] = s.ub[k];
+                if (s.kids_leaf)
+                    for (int c = 0; c < p.d(); ++c)
+                        for (int k = 0; k < p.nx(); ++k) tl.XL[(s.pos * p.d() + c) * p.nx() + k] = -s.xl[c][k];
+            });
+        }
         if (crown_blk) {
             if (!(flags & F_NO_SWEEP))
-                x.each([&](int tid, TState<P> &s) {
+                x.each([&](int tid, TState<P> &s) {   // layout [c of every crown node | e of every crown node]
                     if (!s.active) return;
-                    for (int k = 0; k < p.nx(); ++k) cb[tid * nxu + k] = s.xb[k];
-                    for (int k = 0; k < p.nu(); ++k) cb[tid * nxu + p.nx() + k] = s.ub[k];
+                    for (int k = 0; k < p.nx(); ++k) cb[tid * p.nx() + k] = s.xb[k];
+                    for (int k = 0; k < p.nu(); ++k) cb[nl_grp * p.nx() + tid * p.nu() + k] = s.ub[k];
                 });
             return;
         }
@@ -113,20 +149,117 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     if (MODE == MODE_FULL) x.barrier();   // zbar.s written by the parents is read by the children in phase B
     stamp();   // 2: phase A done
 
-    // ---- S1 sweeps
-    if (!(flags & F_NO_SWEEP) && !crown_blk) {
+    // ---- S1 sweeps, lane-team version (all sweep vectors in LDS)
+    if (sweeping && team) {
+        const int nx = p.nx(), nu = p.nu(), d = p.d(), nthr = x.nthreads();
+        const double *lmB = lm + n_sw;
+        const MatPtr gB = M + dm.mB;
+        auto level_geo = [&](int l, int &lfirst, int &cnt, long &gfirst) {
+            cnt = 1; lfirst = 0;
+            for (int k = 0; k < l; ++k) { lfirst += cnt; cnt *= d; }
+            gfirst = dm.first[root_stage + l] + (long)root_pos * cnt;
+        };
+        if (MODE == MODE_CROWN) {   // c_i, e_i of the crown and q of the subtree roots: coalesced copies
+            const double *qg = a.qroot + (long)inst * dm.nsub * dm.nx;
+            x.each([&](int tid, TState<P> &) {
+                for (int k = tid; k < nl_grp * nx; k += nthr) tl.XQ[k] = cb[k];
+                for (int k = tid; k < nl_grp * nu; k += nthr) tl.ED[k] = cb[nl_grp * nx + k];
+                for (int k = tid; k < ngl_grp * nx; k += nthr) tl.XL[k] = qg[k];
+            });
+        }
+        if (MODE != MODE_SUB_B && !(flags & F_DBG_NO_BWD)) {
+            x.barrier();
+            for (int l = stages - 2; l >= 0; --l) {
+                int lfirst, cnt; long gfirst;
+                level_geo(l, lfirst, cnt, gfirst);
+                if (lds_mats) {
+                    const double *SW = lm + l * dm.sw_stride;
+                    x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
+                } else {
+                    const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
+                    x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
+                }
+                x.barrier();
+            }
+            if (MODE == MODE_SUB_A) {   // q at the subtree root and every d_i -> HBM (level chunks are contiguous)
+                double *q_out = a.qroot + ((long)inst * dm.nsub + g) * dm.nx;
+                double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+                x.each([&](int tid, TState<P> &) {
+                    if (tid < nx) q_out[tid] = tl.XQ[tid];
+                    for (int l = 0; l <= stages - 2; ++l) {
+                        int lfirst, cnt; long gfirst;
+                        level_geo(l, lfirst, cnt, gfirst);
+                        for (int k = tid; k < cnt * nu; k += nthr) db[gfirst * nu + k] = tl.ED[lfirst * nu + k];
+                    }
+                });
+            }
+        }
+        if (MODE != MODE_SUB_A && !(flags & F_DBG_NO_FWD)) {
+            const double *xroot = (MODE == MODE_SUB_B) ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
+            const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+            x.each([&](int tid, TState<P> &) {
+                if (tid < nx) tl.XQ[tid] = xroot[tid];
+                if (MODE == MODE_SUB_B)
+                    for (int l = 0; l <= stages - 2; ++l) {
+                        int lfirst, cnt; long gfirst;
+                        level_geo(l, lfirst, cnt, gfirst);
+                        for (int k = tid; k < cnt * nu; k += nthr) tl.ED[lfirst * nu + k] = db[gfirst * nu + k];
+                    }
+            });
+            x.barrier();
+            for (int l = 0; l <= stages - 2; ++l) {
+                int lfirst, cnt; long gfirst;
+                level_geo(l, lfirst, cnt, gfirst);
+                if (lds_mats) {
+                    const double *SW = lm + l * dm.sw_stride;
+                    x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, lmB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
+                } else {
+                    const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
+                    x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, gB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
+                }
+                x.barrier();
+            }
+            // x_i, u_i and the group leaves' x: coalesced level chunks LDS -> zbar; back into the thread state for phase B
+            x.each([&](int tid, TState<P> &s) {
+                for (int l = 0; l <= stages - 2; ++l) {
+                    int lfirst, cnt; long gfirst;
+                    level_geo(l, lfirst, cnt, gfirst);
+                    for (int k = tid; k < cnt * nx; k += nthr) zo[dm.zx + gfirst * nx + k] = tl.XQ[lfirst * nx + k];
+                    for (int k = tid; k < cnt * nu; k += nthr) zo[dm.zu + gfirst * nu + k] = tl.UL[lfirst * nu + k];
+                }
+                const long gl_first = dm.first[root_stage + stages - 1] + (long)root_pos * ngl_grp;
+                for (int k = tid; k < ngl_grp * nx; k += nthr) zo[dm.zx + gl_first * nx + k] = tl.XL[k];
+                if (s.active) {
+                    for (int k = 0; k < nx; ++k) s.xb[k] = tl.XQ[tid * nx + k];
+                    for (int k = 0; k < nu; ++k) s.ub[k] = tl.UL[tid * nu + k];
+                    if (s.kids_leaf)
+                        for (int c = 0; c < d; ++c)
+                            for (int k = 0; k < nx; ++k) s.xl[c][k] = tl.XL[(s.pos * d + c) * nx + k];
+                }
+            });
+        }
+    }
+
+    // ---- S1 sweeps, one-thread-per-node version (fallback when the team vectors do not fit in LDS)
+    if (sweeping && !team) {
         if (MODE == MODE_CROWN) {
             x.each([&](int tid, TState<P> &s) {
                 if (!s.active) return;
-                for (int k = 0; k < p.nx(); ++k) s.xb[k] = cb[tid * nxu + k];
-                for (int k = 0; k < p.nu(); ++k) s.ub[k] = cb[tid * nxu + p.nx() + k];
+                for (int k = 0; k < p.nx(); ++k) s.xb[k] = cb[tid * p.nx() + k];
+                for (int k = 0; k < p.nu(); ++k) s.ub[k] = cb[nl_grp * p.nx() + tid * p.nu() + k];
             });
         }
         if (MODE != MODE_SUB_B && !(flags & F_DBG_NO_BWD)) {
             const double *qg = (MODE == MODE_CROWN) ? a.qroot + (long)inst * dm.nsub * dm.nx : nullptr;
             double *q_out = (MODE == MODE_SUB_A) ? a.qroot + ((long)inst * dm.nsub + g) * dm.nx : nullptr;
             for (int l = stages - 2; l >= 0; --l) {
-                x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) bwd_node(p, dm, M, root_stage + l, tid, ex, qg, q_out, s); });
+                if (lds_mats) {
+                    const double *SW = lm + l * dm.sw_stride;
+                    x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) bwd_node(p, dm, SW, tid, ex, qg, q_out, s); });
+                } else {
+                    const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
+                    x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) bwd_node(p, dm, SW, tid, ex, qg, q_out, s); });
+                }
                 x.barrier();
                 stamp();   // one per backward level
             }
@@ -146,7 +279,13 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
             }
             const double *xroot = (MODE == MODE_SUB_B) ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
             for (int l = 0; l <= stages - 2; ++l) {
-                x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, M, root_stage + l, tid, ex, xroot, s); });
+                if (lds_mats) {
+                    const double *SW = lm + l * dm.sw_stride, *Bm = lm + n_sw;
+                    x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, SW, Bm, tid, ex, xroot, s); });
+                } else {
+                    const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride, Bm = M + dm.mB;
+                    x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, SW, Bm, tid, ex, xroot, s); });
+                }
                 x.barrier();
                 stamp();   // one per forward level
             }

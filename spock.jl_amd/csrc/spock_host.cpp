@@ -10,6 +10,7 @@
 // Because the reference's ricatti_offline only uses A_w, B_w and the (uniform) tree shape, P_i, K_i and
 // Rtilde_i depend on the STAGE of node i only and ABK_j on (stage, child slot); they are stored per stage.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -136,6 +137,54 @@ int choose_split_stage(int N, int d, int nx) {
     while (t0 < N - 2 && group_threads(d, N - t0) > max_thr) ++t0;
     if (group_threads(d, N - t0) > max_thr || group_threads(d, t0 + 1) > max_thr) return -1;
     return t0;
+}
+
+// Threads, grid, LDS carve-up of one launch.  Team sweeps (spock_device.hpp) are used whenever their LDS vectors fit.
+LaunchGeo launch_geometry(int mode, const Dims &dm) {
+    LaunchGeo g;
+    const int d = dm.d, nx = dm.nx, nu = dm.nu;
+    auto r64 = [](int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; };
+    int stage_sets[2], n_sets = 0;
+    switch (mode) {
+        case MODE_FULL: stage_sets[n_sets++] = dm.N; g.grid_x = 1; break;
+        case MODE_SUB_A: case MODE_SUB_B: stage_sets[n_sets++] = dm.sub_stages; stage_sets[n_sets++] = dm.t0 + 1; g.grid_x = dm.nsub + 1; break;
+        case MODE_CROWN: stage_sets[n_sets++] = dm.t0 + 1; g.grid_x = 1; break;
+        default: stage_sets[n_sets++] = 2; g.grid_x = 1; break;
+    }
+    int nl = 0, widest = 1, max_stages = 2;
+    long team_doubles = 0;
+    for (int k = 0; k < n_sets; ++k) {
+        const int st = stage_sets[k];
+        const int nonleaf = group_threads(d, st), leaves = ipow(d, st - 1);
+        if (nonleaf > nl) nl = nonleaf;
+        if (st > max_stages) max_stages = st;
+        if (st >= 2 && ipow(d, st - 2) > widest) widest = ipow(d, st - 2);
+        const long td = (long)nonleaf * (nx + 2 * nu) + (long)leaves * nx;
+        if (td > team_doubles) team_doubles = td;
+    }
+    int T = 8;
+    while (T < nx || T < nu) T *= 2;
+    const long mats_bytes = ((long)(max_stages - 1) * dm.sw_stride + (long)d * nx * nu) * 8;
+    const long budget = 60 * 1024, tail = 4 * 8;
+    // Lane teams pay off when a node's mat-vecs are big (measured on MI355X: nx = nu = 20, N = 10: 3058 -> 561 us per
+    // iteration).  For the small compile-time shapes (nx <= 8) one thread per node with the vectors in registers and
+    // the matrices in SGPRs is as fast per level and keeps workgroups at one wave, which the batched regime needs
+    // (team sweeps there: 360k -> 218k iterations/s at 512 instances).  SPOCK_AMD_TEAM=1 / 0 overrides.
+    bool want_team = (nx > 8 || nu > 8);
+    if (const char *e = std::getenv("SPOCK_AMD_TEAM")) want_team = (e[0] == '1');
+    g.team = (mode != MODE_FINALIZE && want_team && T <= 64 && team_doubles * 8 + tail <= budget) ? T : 0;
+    g.threads = r64(nl);
+    if (g.team) {
+        int want = r64(g.team * widest);
+        if (want > 512) want = 512;
+        if (want > g.threads) g.threads = want;
+    }
+    if (mode == MODE_FINALIZE) g.threads = 64;
+    g.ex_doubles = g.team ? (int)team_doubles : g.threads * nx;
+    const long base = (long)g.ex_doubles * 8 + tail;
+    g.lds_mats = (mode != MODE_FINALIZE && base + mats_bytes <= budget) ? 1 : 0;
+    g.lds_bytes = (size_t)(base + (g.lds_mats ? mats_bytes : 0));
+    return g;
 }
 
 std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported) {
@@ -292,6 +341,17 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
     for (size_t k = 0; k < Wm.size(); ++k) push(Wm[k].a);
     dm.mV = (int)pool.size();
     for (size_t k = 0; k < Vm.size(); ++k) push(Vm[k].a);
+    // per-stage "sweep blocks" [W_t,c | V_t,c | ABK_{t+1},c | K_t], contiguous over the stages, so that a workgroup can
+    // stage the blocks of its own stages in LDS with one coalesced copy (spock_group.hpp)
+    dm.sw_oW = 0; dm.sw_oV = d * nx * nx; dm.sw_oABK = dm.sw_oV + d * nu * nx; dm.sw_oK = dm.sw_oABK + d * nx * nx;
+    dm.sw_stride = dm.sw_oK + nu * nx;
+    dm.mSweep = (int)pool.size();
+    for (int t = 0; t < N - 1; ++t) {
+        for (int c = 0; c < d; ++c) push(Wm[(size_t)t * d + c].a);
+        for (int c = 0; c < d; ++c) push(Vm[(size_t)t * d + c].a);
+        for (int c = 0; c < d; ++c) push(ABK[(size_t)(t + 1) * d + c].a);
+        push(K[t].a);
+    }
     dm.mLs = push(ls.a);
     out.ls = ls.a;
     dm.mb = push(hp.b);

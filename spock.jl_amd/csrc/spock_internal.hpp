@@ -33,6 +33,8 @@ struct Dims {
     // composite matrices of the restructured S1 recursion (spock_host.cpp): per stage t
     //   U_t (nx x nu), per child slot W_{t,c} (nx x nx), V_{t,c} (nu x nx)
     int mU, mW, mV;
+    // per-stage sweep blocks (offsets inside one block, block stride, pool offset of stage 0)
+    int mSweep, sw_stride, sw_oW, sw_oV, sw_oABK, sw_oK;
     int diag_costs;  // every sqrtQ / sqrtR / sqrtQN is diagonal -> element-wise products in the kernels
 };
 
@@ -89,6 +91,9 @@ struct KArgs {
     int parity;
     unsigned flags;
     int batch;
+    int lds_mats;               // 1: the sweep matrices of the workgroup's stages are staged in LDS
+    int ex_doubles;             // size of the LDS exchange region (thread path: threads*nx; team path: TeamLds vectors)
+    int team;                   // > 0: lane-team sweeps with this many lanes per node (all sweep vectors in LDS)
 };
 
 // ---- SP (SuperMann + Anderson) driver: plain data shared by the kernels (spock_sp.hpp) and the driver ----
@@ -144,6 +149,9 @@ struct BuildProducts {
 // returns "" on success, else an error message; split_stage 0 = choose
 std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported);
 int choose_split_stage(int N, int d, int nx);
+// launch geometry shared by the GPU launcher and the emulation harness
+struct LaunchGeo { int threads, grid_x, team, lds_mats, ex_doubles; size_t lds_bytes; };
+LaunchGeo launch_geometry(int mode, const Dims &dm);
 int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tree with `stages` stages
 
 // ---- kernel launchers (spock_kernels.hip) ---------------------------------------------------------

@@ -5,6 +5,8 @@
 // for run-time dimensions, and launches them on the handle's stream.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "spock_group.hpp"
 #include "spock_sp.hpp"
 
@@ -14,13 +16,14 @@ template <class P>
 struct GpuExec {
     TState<P> st;
     double m[3];
-    double *ex;
+    double *ex, *lm;
     unsigned long long *red;
     int *fl;
     template <class F>
     __device__ __forceinline__ void each(F &&f) { f((int)threadIdx.x, st); }
     __device__ __forceinline__ void barrier() { __syncthreads(); }
     __device__ __forceinline__ double *lds() { return ex; }
+    __device__ __forceinline__ double *lds_mats() { return lm; }
     __device__ __forceinline__ int &flag() { return *fl; }
     __device__ __forceinline__ void stash3(int, const double *mx) { m[0] = mx[0]; m[1] = mx[1]; m[2] = mx[2]; }
     __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
@@ -51,28 +54,26 @@ __global__ void __launch_bounds__(512) spock_group_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpuExec<P> x;
     x.ex = smem;
-    x.red = reinterpret_cast<unsigned long long *>(smem + (size_t)blockDim.x * a.dm.nx);
+    x.red = reinterpret_cast<unsigned long long *>(smem + a.ex_doubles);
     x.fl = reinterpret_cast<int *>(x.red + 3);
+    x.lm = smem + a.ex_doubles + 4;
     group_body<P, MODE>(x, a, (int)blockIdx.y, (int)blockIdx.x);
 }
 
 static inline int round64(int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; }
 
 template <class P>
-static int launch_variant(int mode, const KArgs &a, hipStream_t st) {
-    const Dims &dm = a.dm;
-    int nthr, gx;
-    const int sub_thr = group_threads(dm.d, dm.sub_stages), crown_thr = group_threads(dm.d, dm.t0 + 1);
-    switch (mode) {
-        case MODE_FULL: nthr = group_threads(dm.d, dm.N); gx = 1; break;
-        case MODE_SUB_A: case MODE_SUB_B: nthr = sub_thr > crown_thr ? sub_thr : crown_thr; gx = dm.nsub + 1; break;
-        case MODE_CROWN: nthr = crown_thr; gx = 1; break;
-        default: nthr = 64; gx = 1; break;
-    }
-    const int thr = round64(nthr);
-    if (thr > 512) return (int)hipErrorInvalidConfiguration;
-    const size_t lds = ((size_t)thr * dm.nx + 4) * sizeof(double);
-    const dim3 grid(gx, a.batch), block(thr);
+static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
+    const LaunchGeo g = launch_geometry(mode, a_in.dm);
+    if (g.threads > 512) return (int)hipErrorInvalidConfiguration;
+    KArgs a = a_in;
+    // LDS-staged sweep matrices pay off when many workgroups hide the staging copy (batched regime: +18 % at 512
+    // instances); with a handful of workgroups the copy is pure latency in front of the sweep (+3 us per kernel)
+    bool stage = g.lds_mats && ((long)a.batch * g.grid_x >= 1024 || g.team);
+    if (const char *e = std::getenv("SPOCK_AMD_LDS_MATS")) stage = g.lds_mats && e[0] == '1';
+    a.lds_mats = stage ? 1 : 0; a.team = g.team; a.ex_doubles = g.ex_doubles;
+    const size_t lds = g.lds_bytes;   // sized for the staged matrices either way
+    const dim3 grid(g.grid_x, a.batch), block(g.threads);
     switch (mode) {
         case MODE_FULL: hipLaunchKernelGGL((spock_group_kernel<P, MODE_FULL>), grid, block, lds, st, a); break;
         case MODE_SUB_A: hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_A>), grid, block, lds, st, a); break;

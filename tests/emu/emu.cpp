@@ -25,11 +25,11 @@ static bool env_on(const char *k) { const char *e = std::getenv(k); return e && 
 template <class P>
 struct EmuExec {
     std::vector<TState<P>> st;
-    std::vector<double> ex;
+    std::vector<double> ex, lmv;
     std::vector<std::array<double, 3>> m;
     int fl = 0, nthreads_v = 0;
     bool reverse = false;
-    EmuExec(int thr, int nx) : st(thr), ex((size_t)thr * nx + 8, 0.), m(thr), nthreads_v(thr), reverse(env_on("SPOCK_EMU_REVERSE")) {}
+    EmuExec(int thr, int ex_doubles, size_t nmats) : st(thr), ex((size_t)ex_doubles + 8, 0.), lmv(nmats + 8, 0.), m(thr), nthreads_v(thr), reverse(env_on("SPOCK_EMU_REVERSE")) {}
     template <class F>
     void each(F &&f) {
         if (!reverse) for (int t = 0; t < nthreads_v; ++t) f(t, st[t]);
@@ -37,6 +37,7 @@ struct EmuExec {
     }
     void barrier() {}
     double *lds() { return ex.data(); }
+    double *lds_mats() { return lmv.data(); }
     int &flag() { return fl; }
     void stash3(int tid, const double *mx) { m[tid] = {mx[0], mx[1], mx[2]}; }
     double r3[3] = {0., 0., 0.};
@@ -55,23 +56,18 @@ template <class P, int MODE>
 static void run_blocks(const KArgs &a, int gx, int thr) {
     for (int inst = 0; inst < a.batch; ++inst)
         for (int g = 0; g < gx; ++g) {
-            EmuExec<P> x(thr, a.dm.nx);
+            EmuExec<P> x(thr, a.ex_doubles, (size_t)a.dm.N * a.dm.sw_stride + (size_t)a.dm.d * a.dm.nx * a.dm.nu);
             group_body<P, MODE>(x, a, inst, g);
         }
 }
 
 template <class P>
-static int launch_variant(int mode, const KArgs &a) {
-    const Dims &dm = a.dm;
-    int nthr, gx;
-    const int sub_thr = group_threads(dm.d, dm.sub_stages), crown_thr = group_threads(dm.d, dm.t0 + 1);
-    switch (mode) {
-        case MODE_FULL: nthr = group_threads(dm.d, dm.N); gx = 1; break;
-        case MODE_SUB_A: case MODE_SUB_B: nthr = sub_thr > crown_thr ? sub_thr : crown_thr; gx = dm.nsub + 1; break;
-        case MODE_CROWN: nthr = crown_thr; gx = 1; break;
-        default: nthr = 64; gx = 1; break;
-    }
-    const int thr = round64(nthr);
+static int launch_variant(int mode, const KArgs &a_in) {
+    KArgs a = a_in;
+    const LaunchGeo g = launch_geometry(mode, a.dm);
+    a.lds_mats = env_on("SPOCK_EMU_NO_LDS_MATS") ? 0 : g.lds_mats;
+    a.team = g.team; a.ex_doubles = g.ex_doubles;
+    const int thr = g.threads, gx = g.grid_x;
     if (thr > 512) return 9;
     switch (mode) {
         case MODE_FULL: run_blocks<P, MODE_FULL>(a, gx, thr); break;

@@ -90,6 +90,24 @@ def test_emulated_cp_driver(S, O, emu, name, tol, log):
     m.close()
 
 
+def test_emulated_team_sweeps_match_thread_sweeps(S, O, emu, monkeypatch):
+    """The lane-team S1 sweeps (default for nx > 8) and the one-thread-per-node sweeps are two implementations of the same
+    recursion: force each on a small shape and on a large one and compare with the oracle."""
+    for specs, kw in ((S.get_server_heat_specs(6, 5, 2, nu=2), {"split_stage": 3}), (S.get_random_linear_specs(5, 12, 4), {"split_stage": 2})):
+        flat = S.flatten_problem(*specs)
+        o = O.Oracle(flat, O.CP)
+        rng = np.random.default_rng(11)
+        z = rng.standard_normal(flat.nz); v = rng.standard_normal(flat.nv); x0 = rng.standard_normal(flat.nx) * 0.1
+        zr, vr = o.T(z, v, 0.3, 0.25, x0)
+        for team in ("0", "1"):
+            monkeypatch.setenv("SPOCK_AMD_TEAM", team)
+            m = S.build_model(*specs, lib_path=emu, **kw)
+            zo, vo = m.T(z, v, 0.3, 0.25, x0)
+            assert relerr(zo, zr) <= 1e-12 and relerr(vo, vr) <= 1e-12
+            assert relerr(m.prox_f(z, 0.1, x0), o.prox_f(z, 0.1, x0)) <= 1e-12
+            m.close()
+
+
 def test_emulated_known_answer_trace(S, emu, kat_cp):
     m = S.build_model(*S.get_server_heat_specs(7, 5, 2), lib_path=emu, split_stage=3)
     r = S.solve_model(m, np.full(5, 0.1), tol=1e-5, verbose=S.LOG)
