@@ -91,7 +91,8 @@ typedef struct {
     int32_t device;       /* HIP device ordinal */
     int32_t batch;        /* independent instances (same problem data, own x0 and state) held by the handle; 0 -> 1 */
     int32_t split_stage;  /* tree stage at which the tree is cut into per-workgroup subtrees; 0 = choose */
-    double L_norm;        /* NaN -> the reference's hard-coded value: 10.0 (CP, cpock.jl:63) / 3.28 (SP, models/spock.jl:64) */
+    double L_norm;        /* NaN -> the reference's hard-coded value: 10.0 (CP, cpock.jl:63) / 3.28 (SP, models/spock.jl:64);
+                           * negative -> ||L||^2 in closed form (the reference's `Todo: L norm must be computed efficiently!`) */
     int32_t max_iter;     /* 0 -> reference default: 5000 (cp.jl:190) / 1000 (sp.jl:360) */
     int32_t graph_iters;  /* iterations captured per hipGraph replay; 0 = choose */
 } spock_options_t;
@@ -128,6 +129,13 @@ int spock_sizes(spock_handle_t h, spock_sizes_t *out);
 int spock_solve(spock_handle_t h, const double *x0, double tol, int32_t verbose,
                 const double *z0, const double *v0, double gamma, double sigma, spock_result_t *results);
 
+/* Closed-loop MPC simulation, the Spock branch of examples/server_heat/mpc_simulation.jl:47-54,164-177: `steps`
+ * warm-started solves; after each one u = z[u_inds[1:nu]] is applied and x0 <- A_w x0 + B_w u is evaluated on the
+ * device (no state leaves the GPU between steps).  w_seq: [batch][steps] events in [0, d) (the reference draws
+ * rand(1:d)).  x_traj: [batch][steps+1][nx], u_traj: [batch][steps][nu], results: [batch][steps]; any may be NULL. */
+int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const int32_t *w_seq, double tol, int32_t verbose,
+                       double *x_traj, double *u_traj, spock_result_t *results);
+
 /* model.solver_state.z / .v after a solve (mpc_simulation.jl:50-54): copy-out, [batch][nz] / [batch][nv] */
 int spock_get_z(spock_handle_t h, double *z_out);
 int spock_get_v(spock_handle_t h, double *v_out);
@@ -157,6 +165,8 @@ int spock_op_T(spock_handle_t h, const double *x0, const double *z, const double
  * 3 ABK, 4 kernel projector, 5 sqrtQ, 6 sqrtR, 7 sqrtQN.  *len receives the element count. */
 int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_t cap, int32_t *len);
 
+/* L_norm in use (step sizes default to 0.99/sqrt(L_norm), cp.jl:198-201) and the closed-form ||L||^2 of this problem */
+int spock_L_norm(spock_handle_t h, double *in_use, double *closed_form);
 /* device time of the last solve divided by its iteration count, and that count */
 int spock_get_timing(spock_handle_t h, double *iter_ms_avg, int32_t *iters_timed);
 /* measurement aid (no reference counterpart): runs `reps` further CP iterations on the current state with a

@@ -8,7 +8,7 @@ from .problem import (CONE_NONNEG, CONE_NONPOS, CONE_REALS, CONE_SOC, CONE_ZEROS
                       generate_scenario_tree_uniform_branching_factor_v2, get_uniform_rms_avar_v2,
                       get_uniform_rms_tv_v2, get_uniform_rms_v2)
 from .model import (CP, LOG, SILENT, SP, AlgorithmOptions, Model, QNewtonOptions, SolverOptions, VERBOSE_LEVEL,
-                    build_model, solve_model, solve_model_bang)
+                    build_model, mpc_simulation, solve_model, solve_model_bang)
 from ._lib import SpockError, load_library
 from .examples import L_norm_sq, get_car_fixture, get_random_linear_specs, get_server_heat_specs
 

@@ -53,6 +53,7 @@ SYMBOLS = {
     "spock_destroy": (C.c_int, [_P]),
     "spock_sizes": (C.c_int, [_P, C.POINTER(Sizes)]),
     "spock_solve": (C.c_int, [_P, _P, _D, _I, _P, _P, _D, _D, _P]),
+    "spock_mpc_simulate": (C.c_int, [_P, _P, _I, _P, _D, _I, _P, _P, _P]),
     "spock_get_z": (C.c_int, [_P, _P]),
     "spock_get_v": (C.c_int, [_P, _P]),
     "spock_set_state": (C.c_int, [_P, _P, _P]),
@@ -65,6 +66,7 @@ SYMBOLS = {
     "spock_op_dot": (C.c_int, [_P, _P, _P, _P, _P, _D, _D, C.POINTER(_D)]),
     "spock_op_T": (C.c_int, [_P, _P, _P, _P, _D, _D, _P, _P]),
     "spock_get_build_product": (C.c_int, [_P, _I, _P, _I, C.POINTER(_I)]),
+    "spock_L_norm": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_D)]),
     "spock_get_timing": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_I)]),
     "spock_profile_kernels": (C.c_int, [_P, _I, _P, _P]),
     "spock_debug_stamps": (C.c_int, [_P, _P]),

@@ -213,7 +213,7 @@ int sp_solve(spock_handle_s *h, const double *x0, double tol, int verbose, const
              double gamma, double sigma, spock_result_t *results) {
     const Dims &dm = h->bp.dm;
     const size_t B = (size_t)h->batch, nr = (size_t)dm.nz + dm.nv;
-    RTCHECK(rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream));
+    if (x0) RTCHECK(rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream));   // NULL: x0 is already on the device (MPC loop)
     if (z0) {
         for (size_t b = 0; b < B; ++b) {
             RTCHECK(rt::h2d(h->s_vec[SV_Z] + b * nr, z0 + b * dm.nz, sizeof(double) * dm.nz, h->stream));
@@ -336,6 +336,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     bool unsupported = false;
     const std::string msg = host_build(hp, split, h->bp, unsupported);
     if (!msg.empty()) { delete h; return fail(unsupported ? SPOCK_ERR_UNSUPPORTED : SPOCK_ERR_BUILD, msg); }
+    if (o && o->L_norm < 0.) h->L_norm = h->bp.L_norm_closed * (1. + 1e-9);   // negative: closed form instead of the hard-coded constant
     const Dims &dm = h->bp.dm;
 
     auto bail = [&](int e, const char *what) {
@@ -401,9 +402,65 @@ int spock_sizes(spock_handle_t h, spock_sizes_t *s) {
     return SPOCK_OK;
 }
 
+static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t verbose, const double *z0, const double *v0,
+                      double gamma, double sigma, spock_result_t *results);
+
 int spock_solve(spock_handle_t h, const double *x0, double tol, int32_t verbose, const double *z0, const double *v0,
                 double gamma, double sigma, spock_result_t *results) {
     if (!h || !x0) return fail(SPOCK_ERR_BAD_ARG, "handle and x0 must not be NULL");
+    return solve_impl(h, x0, tol, verbose, z0, v0, gamma, sigma, results);
+}
+
+// Closed-loop MPC simulation of examples/server_heat/mpc_simulation.jl:47-54,164-177 (Spock branch): `steps` warm-started
+// solves; after each one the first-stage input u = z[u_inds[1:nu]] is applied and the state advanced on the DEVICE,
+// x0 <- A_w x0 + B_w u with the event w = w_seq[b][t] supplied by the caller (the reference draws rand(1:d)).
+int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const int32_t *w_seq, double tol, int32_t verbose,
+                       double *x_traj, double *u_traj, spock_result_t *results) {
+    if (!h || !x0 || !w_seq || steps < 1) return fail(SPOCK_ERR_BAD_ARG, "handle, x0, w_seq must not be NULL and steps >= 1");
+    const Dims &dm = h->bp.dm;
+    const size_t B = (size_t)h->batch;
+    for (size_t k = 0; k < B * (size_t)steps; ++k)
+        if (w_seq[k] < 0 || w_seq[k] >= dm.d) return fail(SPOCK_ERR_BAD_ARG, "w_seq entries must be events in [0, d)");
+    int *d_w = nullptr;
+    double *d_xt = nullptr, *d_ut = nullptr;
+    void *pw = nullptr, *pxt = nullptr, *put = nullptr;
+    RTCHECK(rt::dmalloc(&pw, B * steps * sizeof(int)));
+    RTCHECK(rt::dmalloc(&pxt, B * (steps + 1) * dm.nx * sizeof(double)));
+    RTCHECK(rt::dmalloc(&put, B * steps * dm.nu * sizeof(double)));
+    d_w = (int *)pw; d_xt = (double *)pxt; d_ut = (double *)put;
+    auto cleanup = [&]() { rt::dfree(pw); rt::dfree(pxt); rt::dfree(put); };
+    int rc = SPOCK_OK;
+    do {
+        int e = rt::h2d(d_w, w_seq, B * steps * sizeof(int), h->stream);
+        if (!e) e = rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream);
+        if (e) { rc = fail(SPOCK_ERR_HIP, rt::err(e)); break; }
+        std::vector<spock_result_t> step_res(B);
+        for (int t = 0; t < steps && rc == SPOCK_OK; ++t) {
+            rc = solve_impl(h, nullptr, tol, verbose, nullptr, nullptr, NAN, NAN, step_res.data());
+            if (rc) break;
+            if (results) for (size_t b = 0; b < B; ++b) results[b * steps + t] = step_res[b];
+            MpcArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.dm = dm; a.mats = h->d_mats; a.x0 = h->d_x0; a.w_seq = d_w; a.x_traj = d_xt; a.u_traj = d_ut;
+            a.t = t; a.steps = steps; a.batch = h->batch;
+            if (h->alg == SPOCK_ALG_SP) { a.z = h->s_vec[0]; a.stride_z = (long)dm.nz + dm.nv; }
+            else { a.z = h->d_z[0]; a.stride_z = dm.nz; }
+            e = launch_mpc_advance(a, h->stream);
+            if (e) rc = fail(SPOCK_ERR_HIP, rt::err(e));
+        }
+        if (rc) break;
+        int e2 = 0;
+        if (x_traj) e2 = rt::d2h(x_traj, d_xt, B * (steps + 1) * dm.nx * sizeof(double), h->stream);
+        if (!e2 && u_traj) e2 = rt::d2h(u_traj, d_ut, B * steps * dm.nu * sizeof(double), h->stream);
+        if (!e2) e2 = rt::sync(h->stream);
+        if (e2) rc = fail(SPOCK_ERR_HIP, rt::err(e2));
+    } while (0);
+    cleanup();
+    return rc;
+}
+
+static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t verbose, const double *z0, const double *v0,
+                      double gamma, double sigma, spock_result_t *results) {
     if ((z0 == nullptr) != (v0 == nullptr)) return fail(SPOCK_ERR_BAD_ARG, "z0 and v0 must be given together");  // cpock.jl:180-183
     if (verbose != SPOCK_SILENT && verbose != SPOCK_LOG) return fail(SPOCK_ERR_BAD_ARG, "verbose must be SPOCK_SILENT or SPOCK_LOG");
     if (!(tol >= 0.)) return fail(SPOCK_ERR_BAD_ARG, "tol must be non-negative");
@@ -413,7 +470,7 @@ int spock_solve(spock_handle_t h, const double *x0, double tol, int32_t verbose,
     if (!(gamma > 0. && sigma > 0.)) return fail(SPOCK_ERR_BAD_ARG, "gamma and sigma must be positive");
 
     if (h->alg == SPOCK_ALG_SP) return sp_solve(h, x0, tol, verbose, z0, v0, gamma, sigma, results);
-    RTCHECK(rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream));
+    if (x0) RTCHECK(rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream));   // NULL: x0 is already on the device
     if (z0) {
         RTCHECK(rt::h2d(h->d_z[0], z0, B * dm.nz * sizeof(double), h->stream));
         RTCHECK(rt::h2d(h->d_v[0], v0, B * dm.nv * sizeof(double), h->stream));
@@ -659,6 +716,13 @@ int spock_debug_stamps(spock_handle_t h, uint64_t *out /* [3][64][2] */) {
     if (!h || !out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
     RTCHECK(rt::d2h(out, h->d_dbg, sizeof(uint64_t) * 3 * 64 * 2, h->stream));
     RTCHECK(rt::sync(h->stream));
+    return SPOCK_OK;
+}
+
+int spock_L_norm(spock_handle_t h, double *in_use, double *closed_form) {
+    if (!h) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    if (in_use) *in_use = h->L_norm;
+    if (closed_form) *closed_form = h->bp.L_norm_closed;
     return SPOCK_OK;
 }
 

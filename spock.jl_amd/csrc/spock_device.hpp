@@ -617,6 +617,17 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// closed-loop step (examples/server_heat/mpc_simulation.jl:164-177): u = z[u_inds[1:nu]], x0 <- A_w x0 + B_w u.
+// One thread per instance-row; `row` in [0, nx).
+SPK_DEV double mpc_advance_row(const Dims &dm, MatPtr M, const double *z, const double *x0, int w, int row) {
+    const MatPtr A = M + dm.mA + w * dm.nx * dm.nx, B = M + dm.mB + w * dm.nx * dm.nu;
+    double a = 0., b = 0.;
+    for (int k = 0; k < dm.nx; ++k) a += A[row + k * dm.nx] * x0[k];
+    for (int k = 0; k < dm.nu; ++k) b += B[row + k * dm.nx] * z[dm.zu + k];
+    return a + b;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Termination bookkeeping of run_cp! / should_terminate! (cp.jl:54-123, :205-228), run by ONE thread per
 // instance at the start of an iteration (for the previous one) and by the finalize kernel.
 // Returns true when the instance is finished.

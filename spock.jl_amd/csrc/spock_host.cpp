@@ -321,6 +321,8 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
     auto &pool = out.mats;
     pool.clear();
     auto push = [&](const std::vector<double> &v) { int off = (int)pool.size(); pool.insert(pool.end(), v.begin(), v.end()); return off; };
+    dm.mA = (int)pool.size();
+    for (int w2 = 0; w2 < d; ++w2) push(A[w2].a);
     dm.mB = (int)pool.size();
     for (int w2 = 0; w2 < d; ++w2) push(B[w2].a);
     dm.mK = (int)pool.size();
@@ -369,6 +371,27 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
         return true;
     };
     dm.diag_costs = (all_diag(out.sqrtQ, nx) && all_diag(out.sqrtR, nu) && all_diag(out.sqrtQN, nx)) ? 1 : 0;
+    // ---- ||L||^2 in closed form.  L acts separately on x (non-leaf: v7 and the children's v3; leaf: v14 and v11), on u
+    // (v7, children's v4), on tau (v5, v6), on s_leaf (v12, v13) and on (s_i, y_i) (v1, v2), so L'L is block diagonal:
+    //   ||L||^2 = max{ 1 + lmax(sum_ch Q_j), 1 + lmax(QN_i), 1 + lmax(sum_ch R_j), 1/2, 1 + (beta + sqrt(beta^2 + 4 beta))/2 },
+    // beta = |b|^2.  The reference leaves this as a `Todo` and hard-codes 10.0 (cpock.jl:62-63) / 3.28 (models/spock.jl:63-64).
+    {
+        auto lmax = [&](const Mat &S) { Mat V; std::vector<double> w; sym_eig(S, V, w); double m = 0.; for (double x : w) m = x > m ? x : m; return m; };
+        double best = 0.5, beta = 0.;
+        for (double x : hp.b) beta += x * x;
+        best = std::fmax(best, 1. + 0.5 * (beta + std::sqrt(beta * beta + 4. * beta)));
+        auto Qat = [&](int jn) { return Mat::from(hp.Q.data() + (size_t)(hp.nQ == 1 ? 0 : jn) * nx * nx, nx, nx); };
+        auto Rat = [&](int jn) { return Mat::from(hp.R.data() + (size_t)(hp.nR == 1 ? 0 : jn) * nu * nu, nu, nu); };
+        const int n_par = (hp.nQ == 1 && hp.nR == 1) ? 1 : nn;     // shared costs: every parent has the same sums
+        for (int i = 0; i < n_par; ++i) {
+            Mat sq(nx, nx), sr(nu, nu);
+            for (int c = 0; c < d; ++c) { sq = add(sq, Qat(i * d + c)); sr = add(sr, Rat(i * d + c)); }
+            best = std::fmax(best, 1. + lmax(sq));
+            best = std::fmax(best, 1. + lmax(sr));
+        }
+        for (int i = 0; i < hp.nQN; ++i) best = std::fmax(best, 1. + lmax(Mat::from(hp.QN.data() + (size_t)i * nx * nx, nx, nx)));
+        out.L_norm_closed = best;
+    }
     for (double x : pool) if (!(x == x)) return "build step produced NaN";
     return "";
 }

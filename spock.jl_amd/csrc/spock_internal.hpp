@@ -35,6 +35,7 @@ struct Dims {
     int mU, mW, mV;
     // per-stage sweep blocks (offsets inside one block, block stride, pool offset of stage 0)
     int mSweep, sw_stride, sw_oW, sw_oV, sw_oABK, sw_oK;
+    int mA;          // A_w, d matrices (closed-loop state update of the MPC loop)
     int diag_costs;  // every sqrtQ / sqrtR / sqrtQN is diagonal -> element-wise products in the kernels
 };
 
@@ -145,6 +146,7 @@ struct BuildProducts {
     std::vector<double> mats;  // the matrix pool uploaded to the device
     // copies kept for spock_get_build_product
     std::vector<double> P, K, Rinv, ABK, ls, sqrtQ, sqrtR, sqrtQN;
+    double L_norm_closed = 0.;   // ||L||^2 in closed form; the reference hard-codes 10.0 / 3.28
 };
 // returns "" on success, else an error message; split_stage 0 = choose
 std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported);
@@ -158,6 +160,18 @@ int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tre
 // Each returns a hipError_t cast to int.  `stream` is a hipStream_t.
 int launch_group(int mode, const KArgs &a, void *stream);
 bool have_static_variant(int nx, int nu, int d, int ny);
+// closed-loop step of examples/server_heat/mpc_simulation.jl:164-177 on the device
+struct MpcArgs {
+    Dims dm;
+    const double *mats;
+    const double *z;        // iterate of instance b at z + b * stride_z (the u block of node 0 is the applied input)
+    long stride_z;
+    double *x0;             // [batch][nx], updated in place: x0 <- A_w x0 + B_w u
+    const int *w_seq;       // [batch][steps] events
+    double *x_traj, *u_traj;  // [batch][steps+1][nx], [batch][steps][nu]
+    int t, steps, batch;
+};
+int launch_mpc_advance(const MpcArgs &a, void *stream);
 int launch_sp(const SpArgs &a, void *stream);   // a.op selects the kernel (spock_sp.hpp)
 int sp_flat_blocks(long nr);                    // workgroups per instance of the flat kernels
 int sp_lop_blocks(const Dims &dm);              // workgroups per instance of the LOP kernels

@@ -222,6 +222,29 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
     }
 }
 
+__global__ void __launch_bounds__(64) spock_mpc_advance_kernel(const MpcArgs a) {
+    const int inst = blockIdx.x, r = threadIdx.x;
+    const Dims &dm = a.dm;
+    __shared__ double xs[kDynMaxNx];
+    const double *z = a.z + (long)inst * a.stride_z;
+    double *x0 = a.x0 + (long)inst * dm.nx;
+    const int w = a.w_seq[(long)inst * a.steps + a.t];
+    double xn = 0.;
+    if (r < dm.nx) {
+        if (a.t == 0) a.x_traj[((long)inst * (a.steps + 1)) * dm.nx + r] = x0[r];
+        xn = mpc_advance_row(dm, (MatPtr)a.mats, z, x0, w, r);
+    }
+    if (r < dm.nu) a.u_traj[((long)inst * a.steps + a.t) * dm.nu + r] = z[dm.zu + r];
+    __syncthreads();   // every row has read the old x0
+    if (r < dm.nx) { x0[r] = xn; a.x_traj[((long)inst * (a.steps + 1) + a.t + 1) * dm.nx + r] = xn; }
+    (void)xs;
+}
+
+int launch_mpc_advance(const MpcArgs &a, void *stream) {
+    hipLaunchKernelGGL(spock_mpc_advance_kernel, dim3(a.batch), dim3(64), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 template <class P>
 static int launch_lop(const SpArgs &a, hipStream_t st) {
     const Dims &dm = a.dm;

@@ -95,7 +95,7 @@ class Model:
     """CPOCK / SPOCK equivalent (model.jl:127-131, :228-232) whose state lives on the GPU."""
 
     def __init__(self, flat: FlatProblem, options: SolverOptions, batch: int = 1, device: int = 0,
-                 L_norm: float | None = None, max_iter: int = 0, split_stage: int = 0, graph_iters: int = 0,
+                 L_norm: float | str | None = None, max_iter: int = 0, split_stage: int = 0, graph_iters: int = 0,
                  lib_path: str | None = None):
         self._lib = _lib.load_library(lib_path)
         self.problem_definition = flat
@@ -106,7 +106,7 @@ class Model:
                           _ptr(flat.E), _ptr(flat.F), _ptr(flat.b), len(flat.cone_kind), _ptr(flat.cone_kind),
                           _ptr(flat.cone_dim), flat.x_min, flat.x_max, flat.u_min, flat.u_max)
         op = _lib.Options(int(options.algorithm), int(device), self.batch, int(split_stage),
-                          float("nan") if L_norm is None else float(L_norm), int(max_iter), int(graph_iters))
+                          float("nan") if L_norm is None else (-1.0 if L_norm == "auto" else float(L_norm)), int(max_iter), int(graph_iters))
         h = C.c_void_p()
         _lib.check(self._lib, self._lib.spock_create(C.byref(pr), C.byref(op), C.byref(h)))
         self._h = h
@@ -114,8 +114,10 @@ class Model:
         _lib.check(self._lib, self._lib.spock_sizes(self._h, C.byref(sz)))
         self.sizes = sz
         assert sz.nz == flat.nz and sz.nv == flat.nv
-        default_L = 10.0 if options.algorithm == AlgorithmOptions.CP else 3.28
-        self.solver_state = _SolverState(self, sz.nz, sz.nv, default_L if L_norm is None else float(L_norm))
+        used = C.c_double(0.); closed = C.c_double(0.)
+        _lib.check(self._lib, self._lib.spock_L_norm(self._h, C.byref(used), C.byref(closed)))
+        self.L_norm_closed_form = closed.value
+        self.solver_state = _SolverState(self, sz.nz, sz.nv, used.value)
         self.solver_state_internal = _SolverStateInternal(flat)
         self.results = []
 
@@ -244,3 +246,20 @@ def solve_model(model: Model, x0, tol: float = 1e-3, verbose: VERBOSE_LEVEL = SI
 
 
 solve_model_bang = solve_model   # `solve_model!`
+
+
+def mpc_simulation(model: Model, x0, w_seq, tol: float = 1e-3, verbose: VERBOSE_LEVEL = SILENT):
+    """The Spock branch of examples/server_heat/mpc_simulation.jl:47-54,164-177 as ONE call: len(w_seq[b]) warm-started
+    solves per instance; between solves the first-stage input is applied and x0 advanced on the GPU.
+    w_seq: [batch, steps] events in [0, d).  Returns (x_traj [batch, steps+1, nx], u_traj [batch, steps, nu], results)."""
+    B, nx, nu = model.batch, model.problem_definition.nx, model.problem_definition.nu
+    x0 = np.ascontiguousarray(np.broadcast_to(np.asarray(x0, dtype=np.float64).reshape(-1, nx), (B, nx)))
+    w = np.ascontiguousarray(np.broadcast_to(np.asarray(w_seq, dtype=np.int32).reshape(-1, np.asarray(w_seq).shape[-1]), (B, np.asarray(w_seq).shape[-1])))
+    steps = w.shape[1]
+    xt = np.empty((B, steps + 1, nx)); ut = np.empty((B, steps, nu))
+    res = (_lib.Result * (B * steps))()
+    _lib.check(model._lib, model._lib.spock_mpc_simulate(model._h, _ptr(x0), steps, _ptr(w), float(tol), int(verbose), _ptr(xt), _ptr(ut), res))
+    model._refresh()
+    out = [[{"status": res[b * steps + t].status, "iterations": res[b * steps + t].iterations, "solve_ms": res[b * steps + t].solve_ms}
+            for t in range(steps)] for b in range(B)]
+    return xt, ut, out

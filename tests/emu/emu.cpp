@@ -187,6 +187,23 @@ int launch_sp(const SpArgs &a, void *) {
     return cm == 2 ? emu_lop<DynDims<2>>(a) : cm == 1 ? emu_lop<DynDims<1>>(a) : emu_lop<DynDims<0>>(a);
 }
 
+int launch_mpc_advance(const MpcArgs &a, void *) {
+    const Dims &dm = a.dm;
+    for (int inst = 0; inst < a.batch; ++inst) {
+        const double *z = a.z + (long)inst * a.stride_z;
+        double *x0 = a.x0 + (long)inst * dm.nx;
+        const int w = a.w_seq[(long)inst * a.steps + a.t];
+        std::vector<double> xn(dm.nx);
+        for (int r = 0; r < dm.nx; ++r) {
+            if (a.t == 0) a.x_traj[((long)inst * (a.steps + 1)) * dm.nx + r] = x0[r];
+            xn[r] = mpc_advance_row(dm, (MatPtr)a.mats, z, x0, w, r);
+        }
+        for (int r = 0; r < dm.nu; ++r) a.u_traj[((long)inst * a.steps + a.t) * dm.nu + r] = z[dm.zu + r];
+        for (int r = 0; r < dm.nx; ++r) { x0[r] = xn[r]; a.x_traj[((long)inst * (a.steps + 1) + a.t + 1) * dm.nx + r] = xn[r]; }
+    }
+    return 0;
+}
+
 // ---- spock_rt.hpp on host memory ---------------------------------------------------------------------
 namespace rt {
 int set_device(int) { return 0; }

@@ -211,6 +211,67 @@ def test_emulated_sp_known_answer_trace(S, O, emu, kat_sp):
     m.close(); mc.close()
 
 
+def _mpc_reference_loop(O, flat, specs, alg, x0, w, tol):
+    """examples/server_heat/mpc_simulation.jl:47-54,164-177 with the oracle: solve, apply u = z[u_inds[1:nu]], advance."""
+    o = O.Oracle(flat, alg)
+    A, B = specs[2].A, specs[2].B
+    x = np.array(x0, dtype=np.float64)
+    xs, us, its = [x.copy()], [], []
+    for t in range(len(w)):
+        r = o.solve(x, tol=tol)
+        u = o.z[flat.z_slices()["u"]][:flat.nu].copy()
+        x = A[w[t]] @ x + B[w[t]] @ u
+        xs.append(x.copy()); us.append(u); its.append(r["iterations"])
+    return np.array(xs), np.array(us), its
+
+
+def test_emulated_mpc_closed_loop(S, O, emu):
+    """the closed loop of mpc_simulation.jl as one call with the state advanced on the device."""
+    specs = S.get_server_heat_specs(5, 5, 2)
+    flat = S.flatten_problem(*specs)
+    w = np.random.default_rng(1).integers(0, 2, size=(2, 6))
+    x0 = np.array([[0.1] * 5, [0.12] * 5])
+    m = S.build_model(*specs, S.SolverOptions(S.CP, None), lib_path=emu, batch=2, split_stage=2)
+    xt, ut, res = S.mpc_simulation(m, x0, w, tol=1e-3)
+    for b in range(2):
+        xs, us, its = _mpc_reference_loop(O, flat, specs, O.CP, x0[b], w[b], 1e-3)
+        assert [r["iterations"] for r in res[b]] == its                      # warm starts behave identically
+        assert np.max(np.abs(xt[b] - xs)) <= 1e-9 and np.max(np.abs(ut[b] - us)) <= 1e-9
+    m.close()
+    # SP: trajectories are only comparable at the level of the solve tolerance (chaotic iterates, SURVEY.md 0-3)
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, batch=2, split_stage=2)
+    xt, ut, res = S.mpc_simulation(m, x0, w, tol=1e-3)
+    for b in range(2):
+        xs, us, its = _mpc_reference_loop(O, flat, specs, O.SP, x0[b], w[b], 1e-3)
+        assert all(r["status"] == 0 for r in res[b])
+        assert np.max(np.abs(xt[b] - xs)) <= 5e-2 and np.max(np.abs(ut[b] - us)) <= 5e-2
+    with pytest.raises(S.SpockError):
+        S.mpc_simulation(m, x0, np.full((2, 3), 7), tol=1e-3)               # event out of range
+    m.close()
+
+
+def test_emulated_closed_form_L_norm(S, O, emu):
+    """||L||^2 in closed form (3.2746 for the d = 2 AV@R server_heat data, the value the reference
+    rounds up to its hard-coded 3.28) against power iteration on the oracle's L, and as the step-size source."""
+    for specs in (S.get_server_heat_specs(5, 5, 2), S.get_car_fixture(), S.get_server_heat_specs(4, 4, 3, p_ref=[0.2, 0.3, 0.5])):
+        flat = S.flatten_problem(*specs)
+        m = S.build_model(*specs, lib_path=emu, L_norm="auto")
+        o = O.Oracle(flat, O.CP)
+        z = np.random.default_rng(2).standard_normal(flat.nz); lam = 0.0
+        for _ in range(400):
+            z = o.Lt(o.L(z)); lam = np.linalg.norm(z); z /= lam
+        assert abs(m.L_norm_closed_form - lam) <= 1e-6 * lam
+        assert abs(m.solver_state.L_norm - lam) <= 1e-6 * lam
+        o.L_norm = m.solver_state.L_norm
+        x0 = np.full(flat.nx, 0.1)
+        r = S.solve_model(m, x0, tol=1e-3); ro = o.solve(x0, tol=1e-3)
+        assert r["iterations"] == ro["iterations"] and r["status"] == 0
+        m.close()
+    m = S.build_model(*S.get_server_heat_specs(5, 5, 2), lib_path=emu)
+    assert m.solver_state.L_norm == 10.0 and abs(m.L_norm_closed_form - 3.2746211638) <= 1e-6
+    m.close()
+
+
 def test_unsupported_inputs(S, emu):
     tree, cost, dyn, rms, con = S.get_server_heat_specs(4, 3, 2)
     bad = S.generate_scenario_tree_uniform_branching_factor_v2(4, 2, 3, 3)

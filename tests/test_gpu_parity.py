@@ -186,6 +186,29 @@ def test_reference_solution_properties(S, models):
         assert np.allclose(E.T @ y[5 * i:5 * i + 5], tau[[c - 1 for c in ch]] + s[ch])
 
 
+def test_mpc_closed_loop(S, O):
+    """Device-side closed loop (examples/server_heat/mpc_simulation.jl:47-54,164-177, Spock branch) against the same
+    loop driven through the oracle: identical per-step iteration counts (warm starts), trajectories to 1e-8."""
+    specs = S.get_server_heat_specs(8, 5, 2)
+    flat = S.flatten_problem(*specs)
+    w = np.random.default_rng(4).integers(0, 2, size=(3, 5))
+    x0 = np.array([[0.1] * 5, [0.12] * 5, [0.05, 0.1, 0.1, 0.0, 0.1]])
+    m = S.build_model(*specs, S.SolverOptions(S.CP, None), batch=3, split_stage=4)
+    xt, ut, res = S.mpc_simulation(m, x0, w, tol=1e-3)
+    A, B = specs[2].A, specs[2].B
+    for b in range(3):
+        o = O.Oracle(flat, O.CP)
+        x = x0[b].copy()
+        for t in range(5):
+            r = o.solve(x, tol=1e-3)
+            u = o.z[flat.z_slices()["u"]][:5].copy()
+            assert res[b][t]["iterations"] == r["iterations"]
+            assert np.max(np.abs(xt[b, t] - x)) <= 1e-8 and np.max(np.abs(ut[b, t] - u)) <= 1e-8
+            x = A[w[b, t]] @ x + B[w[b, t]] @ u
+        assert np.max(np.abs(xt[b, 5] - x)) <= 1e-8
+    m.close()
+
+
 def test_determinism_and_batch(S, O):
     specs = S.get_server_heat_specs(8, 5, 2)
     flat = S.flatten_problem(*specs)
