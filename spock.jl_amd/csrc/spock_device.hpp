@@ -52,6 +52,7 @@ template <int NX, int NU, int D, int NY, int CM>
 struct StaticDims {
     static constexpr int MAXNX = NX, MAXNU = NU, MAXD = D, MAXNY = NY, MAXM = NY + 2 * D, UNR = 128;
     static constexpr bool DIAG = (CM == CM_SHARED_DIAG), SHARED = (CM != CM_GENERAL);
+    static constexpr bool REGROWS = (NX <= 8 && NU <= 8);   // register-resident team sweep available
     SPK_DEV explicit StaticDims(const Dims &) {}
     SPK_DEV constexpr int nx() const { return NX; }
     SPK_DEV constexpr int nu() const { return NU; }
@@ -63,6 +64,7 @@ struct DynDims {
     static constexpr int MAXNX = kDynMaxNx, MAXNU = kDynMaxNu, MAXD = kDynMaxD, MAXNY = kDynMaxNy,
                          MAXM = kDynMaxNy + 2 * kDynMaxD, UNR = 1;
     static constexpr bool DIAG = (CM == CM_SHARED_DIAG), SHARED = (CM != CM_GENERAL);
+    static constexpr bool REGROWS = false;
     int nx_, nu_, d_, ny_;
     SPK_DEV explicit DynDims(const Dims &dm) : nx_(dm.nx), nu_(dm.nu), d_(dm.d), ny_(dm.ny) {}
     SPK_DEV int nx() const { return nx_; }
@@ -83,6 +85,12 @@ struct TState {
     double ub[P::MAXNU];      // phase A: e_i = Rt^-1 ubar_i       -> u_i
     double dd[P::MAXNU];      // d_i of the Riccati recursion
     double xl[P::MAXD][P::MAXNX];  // leaf children: xbar_j -> x_j
+    // register-resident lane-team sweep (small compile-time shapes): this thread = (node tn_li, matrix row tn_r)
+    // and keeps ITS rows of the sweep matrices of its node's stage for the whole kernel
+    int tn_li, tn_r, tn_lvl, tn_pos;
+    double tW[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNX : 1], tV[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNX : 1];
+    double tA[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNX : 1], tB[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNU : 1];
+    double tK[P::REGROWS ? P::MAXNX : 1];
 };
 
 SPK_DEV double spk_max_nan(double m, double a) { return (a > m || a != a) ? a : m; }  // NaN-propagating max
@@ -379,6 +387,72 @@ SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Register-resident lane-team sweep (P::REGROWS).  Thread w <-> (node li = w / T, row r = w % T) for the WHOLE sweep;
+// it loads its rows of W, V, ABK, B, K of its node's stage once, up front, so that a tree level costs one LDS read of
+// the children's / parent's vector, ~2 d nx FMAs, one LDS write and the barrier -- no memory access on the dependent
+// path.  Needs T * (group non-leaf nodes) <= workgroup size; vectors in LDS as for the other team sweep (TeamLds).
+template <class P>
+SPK_DEV void team_reg_init(const P &p, const Dims &dm, MatPtr M, int root_stage, int stages, int T, int tid, TState<P> &s) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d();
+    const int li = tid / T, r = tid - li * T;
+    int lvl = 0, first = 0, cnt = 1;
+    while (lvl < stages - 1 && li >= first + cnt) { first += cnt; cnt *= d; ++lvl; }
+    const bool ok = (lvl < stages - 1) && (r < nx || r < nu);
+    s.tn_li = ok ? li : -1; s.tn_r = r; s.tn_lvl = lvl; s.tn_pos = li - first;
+    if (!ok) return;
+    const MatPtr SW = M + dm.mSweep + (root_stage + lvl) * dm.sw_stride;
+    SPK_UNROLL for (int c = 0; c < d; ++c) {
+        const MatPtr W = SW + dm.sw_oW + c * nx * nx, V = SW + dm.sw_oV + c * nu * nx, A = SW + dm.sw_oABK + c * nx * nx;
+        const MatPtr B = M + dm.mB + slot_event(c, d) * nx * nu;
+        SPK_UNROLL for (int k = 0; k < nx; ++k) {
+            s.tW[c][k] = (r < nx) ? W[r + k * nx] : 0.;
+            s.tA[c][k] = (r < nx) ? A[r + k * nx] : 0.;
+            s.tV[c][k] = (r < nu) ? V[r + k * nu] : 0.;
+        }
+        SPK_UNROLL for (int k = 0; k < nu; ++k) s.tB[c][k] = (r < nx) ? B[r + k * nx] : 0.;
+    }
+    const MatPtr K = SW + dm.sw_oK;
+    SPK_UNROLL for (int k = 0; k < nx; ++k) s.tK[k] = (r < nu) ? K[r + k * nu] : 0.;
+}
+
+template <class P>
+SPK_DEV void bwd_team_reg(const P &p, int stages, const TeamLds &L, const TState<P> &s) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d(), li = s.tn_li, r = s.tn_r;
+    const bool kg = (s.tn_lvl == stages - 2);
+    double q = (r < nx) ? L.XQ[li * nx + r] : 0., dd = (r < nu) ? L.ED[li * nu + r] : 0.;
+    SPK_UNROLL for (int c = 0; c < d; ++c) {
+        const double *qc = kg ? L.XL + (s.tn_pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
+        SPK_UNROLL for (int k = 0; k < nx; ++k) { const double v = qc[k]; q += s.tW[c][k] * v; dd -= s.tV[c][k] * v; }
+    }
+    if (r < nx) L.XQ[li * nx + r] = q;
+    if (r < nu) L.ED[li * nu + r] = dd;
+}
+
+template <class P>
+SPK_DEV void fwd_team_reg(const P &p, int stages, const TeamLds &L, const TState<P> &s) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d(), li = s.tn_li, r = s.tn_r;
+    const bool kg = (s.tn_lvl == stages - 2);
+    const double *xi = L.XQ + li * nx, *di = L.ED + li * nu;
+    double xv[P::MAXNX], dv[P::MAXNU];
+    SPK_UNROLL for (int k = 0; k < nx; ++k) xv[k] = xi[k];
+    SPK_UNROLL for (int k = 0; k < nu; ++k) dv[k] = di[k];
+    if (r < nx) {
+        SPK_UNROLL for (int c = 0; c < d; ++c) {
+            double a = 0., b2 = 0.;
+            SPK_UNROLL for (int k = 0; k < nx; ++k) a += s.tA[c][k] * xv[k];
+            SPK_UNROLL for (int k = 0; k < nu; ++k) b2 += s.tB[c][k] * dv[k];
+            double *dst = kg ? L.XL + (s.tn_pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
+            dst[r] = a + b2;
+        }
+    }
+    if (r < nu) {
+        double a = 0.;
+        SPK_UNROLL for (int k = 0; k < nx; ++k) a += s.tK[k] * xv[k];
+        L.UL[li * nu + r] = a + dv[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // phase B, node-local.  zb = zbar (x_i, u_i and the leaf x_j come from the thread state unless
 // F_NO_SWEEP), z/v = the input iterate, vo = vbar.  mx[0..2] accumulate |xi_1|, |xi_2|, |xi| maxima.
 struct ProxScal {
@@ -443,15 +517,42 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
             nv2 = t2;
         } else {
             SPK_UNROLL for (int k = 0; k < ny; ++k) { t1[k] = t1[k] * isg; pr[k] = t1[k]; }
-            // projection onto the dual cone, sub-cone by sub-cone (implicit_l.jl:833-845)
-            int off = 0;
-            for (int cn = 0; cn < dm.n_cones; ++cn) {
-                const int kind = dm.cone_kind[cn], dim = dm.cone_dim[cn];
-                if (kind == 0) { for (int k = 0; k < dim; ++k) pr[off + k] = 0.; }
-                else if (kind == 1) { for (int k = 0; k < dim; ++k) if (pr[off + k] < 0.) pr[off + k] = 0.; }
-                else if (kind == 2) { for (int k = 0; k < dim; ++k) if (pr[off + k] > 0.) pr[off + k] = 0.; }
-                else if (kind == 4) project_soc<P::MAXNY>(pr + off, dim);
-                off += dim;
+            // projection onto the dual cone, sub-cone by sub-cone (implicit_l.jl:833-845).  Without second-order
+            // sub-cones it is element-wise: the per-element kind mask keeps pr[] in registers (no dynamic indexing).
+            if (!dm.risk_has_soc) {
+                SPK_UNROLL for (int k = 0; k < ny; ++k) {
+                    const int kind = (dm.elem_kind_mask >> (2 * k)) & 3;
+                    const double v0 = pr[k];
+                    pr[k] = kind == 0 ? 0. : (kind == 1 ? (v0 < 0. ? 0. : v0) : (kind == 2 ? (v0 > 0. ? 0. : v0) : v0));
+                }
+            } else {
+                // general path (second-order sub-cones present): predicated, statically indexed loops so that pr[]
+                // stays in registers (a dynamically indexed local array would put the whole kernel on scratch memory)
+                int off = 0;
+                for (int cn = 0; cn < dm.n_cones; ++cn) {
+                    const int kind = dm.cone_kind[cn], dim = dm.cone_dim[cn];
+                    double t = 0., ss = 0.;
+                    SPK_UNROLL for (int k = 0; k < ny; ++k) {
+                        if (k == off) t = pr[k];
+                        if (k > off && k < off + dim) ss += pr[k] * pr[k];
+                    }
+                    const double x_norm = sqrt(ss);
+                    // SOC (t; x): keep | zero | scale  (risk_measures.jl:47-71)
+                    const bool keep = (x_norm <= t), zero = !keep && (x_norm <= -t);
+                    const double t2 = (t + x_norm) / 2., sc = t2 / x_norm;
+                    SPK_UNROLL for (int k = 0; k < ny; ++k) {
+                        if (k < off || k >= off + dim) continue;
+                        const double v0 = pr[k];
+                        double r;
+                        if (kind == 0) r = 0.;
+                        else if (kind == 1) r = v0 < 0. ? 0. : v0;
+                        else if (kind == 2) r = v0 > 0. ? 0. : v0;
+                        else if (kind == 4) r = keep ? v0 : (zero ? 0. : (k == off ? t2 : sc * v0));
+                        else r = v0;
+                        pr[k] = r;
+                    }
+                    off += dim;
+                }
             }
             SPK_UNROLL for (int k = 0; k < ny; ++k) pr[k] = sg * (t1[k] - pr[k]);
             t2 = t2 * isg;
@@ -633,31 +734,37 @@ SPK_DEV double mpc_advance_row(const Dims &dm, MatPtr M, const double *z, const 
 // Returns true when the instance is finished.
 SPK_DEV bool ctl_prologue(Ctl &c, double x1, double x2, double x3, double *hist, int hist_cap, int parity,
                           bool start_next) {
+    // every field is read once into a scalar and written back once where it changed (a struct copy would live in scratch)
     if (c.done) return true;
     if (c.pending) {
-        const bool log = (c.log_mode == 2);
+        const int log_mode = c.log_mode, alg = c.alg, max_iter = c.max_iter;
+        const double tol = c.tol, r0 = c.res0[0], r1 = c.res0[1];
+        int evals = c.evals, iter = c.iter;
+        const bool log = (log_mode == 2);
         double xi = NAN;
-        if (log) xi = (c.alg == 1) ? x3 : (x1 > x2 ? x1 : x2);   // cp.jl:83-86 / sp.jl:308
+        if (log) xi = (alg == 1) ? x3 : (x1 > x2 ? x1 : x2);   // cp.jl:83-86 / sp.jl:308
         c.xi1 = x1; c.xi2 = x2; c.xi = xi;
-        if (hist && c.evals < hist_cap) {
-            double *h = hist + (long)c.evals * kHistStride;
+        if (hist && evals < hist_cap) {
+            double *h = hist + (long)evals * kHistStride;
             h[0] = xi; h[1] = x1; h[2] = x2; h[3] = 0.;
         }
-        c.evals += 1;
+        evals += 1;
+        c.evals = evals;
         c.pending = 0;
         bool term;
-        if (log) term = (xi <= c.tol);
+        if (log) term = (xi <= tol);
         else {
-            const double t1 = c.tol * c.res0[0] > c.tol ? c.tol * c.res0[0] : c.tol;   // max(tol*res_0, tol)
-            const double t2 = c.tol * c.res0[1] > c.tol ? c.tol * c.res0[1] : c.tol;
+            const double t1 = tol * r0 > tol ? tol * r0 : tol;   // max(tol*res_0, tol)
+            const double t2 = tol * r1 > tol ? tol * r1 : tol;
             term = (x1 <= t1 && x2 <= t2);
         }
-        if (c.res0[0] == -INFINITY) c.res0[0] = x1;
-        if (c.res0[1] == -INFINITY) c.res0[1] = x2;
+        if (r0 == -INFINITY) c.res0[0] = x1;
+        if (r1 == -INFINITY) c.res0[1] = x2;
         if (x1 != x1 || x2 != x2) { c.done = 1; c.status = 2; c.result_parity = parity; return true; }
         if (term) { c.done = 1; c.status = 0; c.result_parity = parity; return true; }
-        c.iter += 1;
-        if (c.iter >= c.max_iter) { c.done = 1; c.status = 1; c.result_parity = parity; return true; }
+        iter += 1;
+        c.iter = iter;
+        if (iter >= max_iter) { c.done = 1; c.status = 1; c.result_parity = parity; return true; }
     }
     if (start_next) c.pending = 1;
     return false;

@@ -41,11 +41,18 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
     int stamp_idx = 0;
     auto stamp = [&]() {
-        if ((flags & F_DBG_STAMPS) && a.dbg && inst == 0 && g == 0 && stamp_idx < 64) {
-            unsigned long long *d = a.dbg + ((long)(MODE == MODE_SUB_A ? 0 : (MODE == MODE_CROWN ? 1 : 2)) * 64 + stamp_idx) * 2;
-            x.each([&](int tid, TState<P> &) { if (tid == 0) x.clocks(d); });
-        }
+        // stamps go to LDS (a global store in front of a barrier would make the barrier wait for its acknowledgement
+        // and distort the segment being measured); dump_stamps() copies them out at the end
+        if ((flags & F_DBG_STAMPS) && a.dbg && inst == 0 && g == 0 && stamp_idx < 64)
+            x.each([&](int tid, TState<P> &) { if (tid == 0) x.clocks(x.stamp_lds() + 2 * stamp_idx); });
         ++stamp_idx;
+    };
+    auto dump_stamps = [&]() {
+        if ((flags & F_DBG_STAMPS) && a.dbg && inst == 0 && g == 0) {
+            unsigned long long *d = a.dbg + (long)(MODE == MODE_SUB_A ? 0 : (MODE == MODE_CROWN ? 1 : 2)) * 128;
+            const int n = stamp_idx < 64 ? stamp_idx : 64;
+            x.each([&](int tid, TState<P> &) { if (tid == 0) for (int k = 0; k < 2 * n; ++k) d[k] = x.stamp_lds()[k]; });
+        }
     };
     stamp();   // 0: entry
 
@@ -63,11 +70,9 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 x.reduce3();
             }
             x.each([&](int tid, TState<P> &) {
-                if (tid == 0) {   // work on a register copy: one load and one store of the block instead of a dependent chain
+                if (tid == 0) {
                     double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
-                    Ctl c = ctl;
-                    x.flag() = ctl_prologue(c, x.red3(0), x.red3(1), x.red3(2), hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
-                    ctl = c;
+                    x.flag() = ctl_prologue(ctl, x.red3(0), x.red3(1), x.red3(2), hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
                 }
             });
             x.barrier();
@@ -102,7 +107,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // ---- stage the sweep matrices of this group's stages (and B) in LDS: one coalesced copy instead of a
     //      dependent matrix fetch in front of every tree level (measured 0.65 / 1.25 us per level without it)
     const bool sweeping = !(flags & F_NO_SWEEP) && !crown_blk;
-    const bool lds_mats = a.lds_mats && sweeping;
+    const bool lds_mats = a.lds_mats && sweeping && !(P::REGROWS && a.team_reg);
     double *lm = x.lds_mats();
     const int n_sw = (stages - 1) * dm.sw_stride, n_b = p.d() * p.nx() * p.nu();
     if (lds_mats) {
@@ -122,6 +127,11 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     for (int k = 0; k < stages - 1; ++k) ngl_grp *= p.d();
     TeamLds tl;
     tl.XQ = ex; tl.ED = tl.XQ + nl_grp * p.nx(); tl.UL = tl.ED + nl_grp * p.nu(); tl.XL = tl.UL + nl_grp * p.nu();
+
+    // register-resident variant of the team sweep: rows of this thread's node in registers, loaded before phase A so that
+    // their latency hides behind it
+    const bool team_reg = P::REGROWS && team > 0 && a.team_reg && (team * nl_grp <= x.nthreads());
+    if (team_reg) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s); });
 
     // ---- phase A (node-local)
     if ((MODE == MODE_FULL || MODE == MODE_SUB_A) && !(flags & F_NO_ALOCAL)) {
@@ -169,10 +179,13 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         }
         if (MODE != MODE_SUB_B && !(flags & F_DBG_NO_BWD)) {
             x.barrier();
+            stamp();   // team vectors in LDS
             for (int l = stages - 2; l >= 0; --l) {
                 int lfirst, cnt; long gfirst;
                 level_geo(l, lfirst, cnt, gfirst);
-                if (lds_mats) {
+                if (team_reg) {
+                    x.each([&](int, TState<P> &s) { if (s.tn_li >= 0 && s.tn_lvl == l) bwd_team_reg(p, stages, tl, s); });
+                } else if (lds_mats) {
                     const double *SW = lm + l * dm.sw_stride;
                     x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 } else {
@@ -180,6 +193,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 }
                 x.barrier();
+                stamp();   // one per backward level
             }
             if (MODE == MODE_SUB_A) {   // q at the subtree root and every d_i -> HBM (level chunks are contiguous)
                 double *q_out = a.qroot + ((long)inst * dm.nsub + g) * dm.nx;
@@ -207,10 +221,13 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     }
             });
             x.barrier();
+            stamp();   // forward inputs in LDS
             for (int l = 0; l <= stages - 2; ++l) {
                 int lfirst, cnt; long gfirst;
                 level_geo(l, lfirst, cnt, gfirst);
-                if (lds_mats) {
+                if (team_reg) {
+                    x.each([&](int, TState<P> &s) { if (s.tn_li >= 0 && s.tn_lvl == l) fwd_team_reg(p, stages, tl, s); });
+                } else if (lds_mats) {
                     const double *SW = lm + l * dm.sw_stride;
                     x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, lmB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 } else {
@@ -218,6 +235,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, gB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 }
                 x.barrier();
+                stamp();   // one per forward level
             }
             // x_i, u_i and the group leaves' x: coalesced level chunks LDS -> zbar; back into the thread state for phase B
             x.each([&](int tid, TState<P> &s) {
@@ -313,6 +331,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + tid] = x.red3(tid); });
         stamp();   // phase B done
     }
+    dump_stamps();
 }
 
 }  // namespace spock

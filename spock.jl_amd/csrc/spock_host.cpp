@@ -140,7 +140,7 @@ int choose_split_stage(int N, int d, int nx) {
 }
 
 // Threads, grid, LDS carve-up of one launch.  Team sweeps (spock_device.hpp) are used whenever their LDS vectors fit.
-LaunchGeo launch_geometry(int mode, const Dims &dm) {
+LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     LaunchGeo g;
     const int d = dm.d, nx = dm.nx, nu = dm.nu;
     auto r64 = [](int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; };
@@ -165,16 +165,26 @@ LaunchGeo launch_geometry(int mode, const Dims &dm) {
     int T = 8;
     while (T < nx || T < nu) T *= 2;
     const long mats_bytes = ((long)(max_stages - 1) * dm.sw_stride + (long)d * nx * nu) * 8;
-    const long budget = 60 * 1024, tail = 4 * 8;
+    const long budget = 60 * 1024, tail = (4 + 128) * 8;   // reduction scratch + flag + 64 diagnostic clock stamps
     // Lane teams pay off when a node's mat-vecs are big (measured on MI355X: nx = nu = 20, N = 10: 3058 -> 561 us per
     // iteration).  For the small compile-time shapes (nx <= 8) one thread per node with the vectors in registers and
     // the matrices in SGPRs is as fast per level and keeps workgroups at one wave, which the batched regime needs
     // (team sweeps there: 360k -> 218k iterations/s at 512 instances).  SPOCK_AMD_TEAM=1 / 0 overrides.
+    // Small shapes in the LATENCY regime (few workgroups in flight) use the register-resident team sweep: thread =
+    // (node, matrix row), the rows live in registers, a tree level is ~0.1-0.2 us instead of 0.7-1.0 us.  It needs
+    // T x (non-leaf nodes of the group) threads; the crown kernel (one workgroup per instance) always qualifies.
     bool want_team = (nx > 8 || nu > 8);
+    const bool small = (nx <= 8 && nu <= 8);
+    const long wgs = (long)batch * g.grid_x;
+    bool want_reg = small && (long)T * nl <= 512 && (mode == MODE_CROWN || wgs < 512);
     if (const char *e = std::getenv("SPOCK_AMD_TEAM")) want_team = (e[0] == '1');
-    g.team = (mode != MODE_FINALIZE && want_team && T <= 64 && team_doubles * 8 + tail <= budget) ? T : 0;
+    if (const char *e = std::getenv("SPOCK_AMD_TEAM_REG")) want_reg = small && (long)T * nl <= 512 && (e[0] == '1');
+    g.team_reg = 0;
+    if (mode != MODE_FINALIZE && want_reg && team_doubles * 8 + tail <= budget) { g.team = T; g.team_reg = 1; }
+    else g.team = (mode != MODE_FINALIZE && want_team && T <= 64 && team_doubles * 8 + tail <= budget) ? T : 0;
     g.threads = r64(nl);
-    if (g.team) {
+    if (g.team_reg) g.threads = r64(g.team * nl);
+    else if (g.team) {
         int want = r64(g.team * widest);
         if (want > 512) want = 512;
         if (want > g.threads) g.threads = want;
@@ -227,6 +237,12 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
         csum += hp.cone_dim[k];
     }
     if (csum != ny) return "cone dimensions must add up to length(b)";
+    dm.risk_has_soc = 0; dm.elem_kind_mask = 0ull;
+    for (int k = 0, e = 0; k < dm.n_cones; ++k)
+        for (int q = 0; q < dm.cone_dim[k]; ++q, ++e) {
+            if (dm.cone_kind[k] == 4) dm.risk_has_soc = 1;
+            dm.elem_kind_mask |= (unsigned long long)(dm.cone_kind[k] & 3) << (2 * e);
+        }
     dm.x_min = hp.x_min; dm.x_max = hp.x_max; dm.u_min = hp.u_min; dm.u_max = hp.u_max;
     for (int t = 0; t <= N; ++t) dm.first[t] = (ipow(d, t) - 1) / (d - 1);
 

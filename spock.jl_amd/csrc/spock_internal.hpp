@@ -23,6 +23,8 @@ struct Dims {
     int n_cones;
     int cone_kind[kMaxCones];  // already the DUAL cone kinds (MOI.dual_set, implicit_l.jl:841)
     int cone_dim[kMaxCones];
+    int risk_has_soc;          // a second-order sub-cone is present (general projection path)
+    unsigned long long elem_kind_mask;  // 2 bits per element of y: dual-cone kind (0 zero, 1 >= 0, 2 <= 0, 3 free), ny <= 16
     double x_min, x_max, u_min, u_max;
     // tree tiling: the tree is cut at stage t0 into nsub = d^t0 subtrees of sub_stages = N - t0 stages
     // (one workgroup each) plus the crown (stages 0..t0, one workgroup).  t0 == 0: one workgroup per instance.
@@ -94,6 +96,7 @@ struct KArgs {
     int batch;
     int lds_mats;               // 1: the sweep matrices of the workgroup's stages are staged in LDS
     int ex_doubles;             // size of the LDS exchange region (thread path: threads*nx; team path: TeamLds vectors)
+    int team_reg;               // lane-team sweep with the matrix rows in registers (small compile-time shapes)
     int team;                   // > 0: lane-team sweeps with this many lanes per node (all sweep vectors in LDS)
 };
 
@@ -152,8 +155,8 @@ struct BuildProducts {
 std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported);
 int choose_split_stage(int N, int d, int nx);
 // launch geometry shared by the GPU launcher and the emulation harness
-struct LaunchGeo { int threads, grid_x, team, lds_mats, ex_doubles; size_t lds_bytes; };
-LaunchGeo launch_geometry(int mode, const Dims &dm);
+struct LaunchGeo { int threads, grid_x, team, team_reg, lds_mats, ex_doubles; size_t lds_bytes; };
+LaunchGeo launch_geometry(int mode, const Dims &dm, int batch);
 int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tree with `stages` stages
 
 // ---- kernel launchers (spock_kernels.hip) ---------------------------------------------------------

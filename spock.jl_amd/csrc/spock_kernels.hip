@@ -17,7 +17,7 @@ struct GpuExec {
     TState<P> st;
     double m[3];
     double *ex, *lm;
-    unsigned long long *red;
+    unsigned long long *red, *stamps;
     int *fl;
     template <class F>
     __device__ __forceinline__ void each(F &&f) { f((int)threadIdx.x, st); }
@@ -27,6 +27,7 @@ struct GpuExec {
     __device__ __forceinline__ int &flag() { return *fl; }
     __device__ __forceinline__ void stash3(int, const double *mx) { m[0] = mx[0]; m[1] = mx[1]; m[2] = mx[2]; }
     __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
+    __device__ __forceinline__ unsigned long long *stamp_lds() { return stamps; }
     __device__ __forceinline__ void clocks(unsigned long long *d) { d[0] = __builtin_readcyclecounter(); d[1] = __builtin_amdgcn_s_memrealtime(); }
     // values are |.| (sign bit clear) or NaN: the unsigned order of the bit patterns is the
     // NaN-propagating max order, so an integer max does the reduction
@@ -56,22 +57,27 @@ __global__ void __launch_bounds__(512) spock_group_kernel(const KArgs a) {
     x.ex = smem;
     x.red = reinterpret_cast<unsigned long long *>(smem + a.ex_doubles);
     x.fl = reinterpret_cast<int *>(x.red + 3);
-    x.lm = smem + a.ex_doubles + 4;
+    x.stamps = reinterpret_cast<unsigned long long *>(smem + a.ex_doubles + 4);
+    x.lm = smem + a.ex_doubles + 4 + 128;
+    const bool wave_stamps = (a.flags & F_DBG_STAMPS) && a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && MODE != MODE_FINALIZE;
+    unsigned long long *wd = a.dbg ? a.dbg + (long)(MODE == MODE_SUB_A ? 0 : (MODE == MODE_CROWN ? 1 : 2)) * 128 : nullptr;
+    if (wave_stamps) wd[2 * (40 + (threadIdx.x >> 6)) + 1] = __builtin_amdgcn_s_memrealtime();
     group_body<P, MODE>(x, a, (int)blockIdx.y, (int)blockIdx.x);
+    if (wave_stamps) wd[2 * (50 + (threadIdx.x >> 6)) + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 static inline int round64(int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; }
 
 template <class P>
 static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
-    const LaunchGeo g = launch_geometry(mode, a_in.dm);
+    const LaunchGeo g = launch_geometry(mode, a_in.dm, a_in.batch);
     if (g.threads > 512) return (int)hipErrorInvalidConfiguration;
     KArgs a = a_in;
     // LDS-staged sweep matrices pay off when many workgroups hide the staging copy (batched regime: +18 % at 512
     // instances); with a handful of workgroups the copy is pure latency in front of the sweep (+3 us per kernel)
     bool stage = g.lds_mats && ((long)a.batch * g.grid_x >= 1024 || g.team);
     if (const char *e = std::getenv("SPOCK_AMD_LDS_MATS")) stage = g.lds_mats && e[0] == '1';
-    a.lds_mats = stage ? 1 : 0; a.team = g.team; a.ex_doubles = g.ex_doubles;
+    a.lds_mats = stage ? 1 : 0; a.team = g.team; a.team_reg = g.team_reg; a.ex_doubles = g.ex_doubles;
     const size_t lds = g.lds_bytes;   // sized for the staged matrices either way
     const dim3 grid(g.grid_x, a.batch), block(g.threads);
     switch (mode) {

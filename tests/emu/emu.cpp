@@ -42,6 +42,8 @@ struct EmuExec {
     void stash3(int tid, const double *mx) { m[tid] = {mx[0], mx[1], mx[2]}; }
     double r3[3] = {0., 0., 0.};
     int nthreads() const { return nthreads_v; }
+    unsigned long long stamps_v[128] = {0};
+    unsigned long long *stamp_lds() { return stamps_v; }
     void clocks(unsigned long long *d) { d[0] = 0; d[1] = 0; }
     void reduce3() {
         for (int k = 0; k < 3; ++k) r3[k] = 0.;
@@ -64,9 +66,9 @@ static void run_blocks(const KArgs &a, int gx, int thr) {
 template <class P>
 static int launch_variant(int mode, const KArgs &a_in) {
     KArgs a = a_in;
-    const LaunchGeo g = launch_geometry(mode, a.dm);
+    const LaunchGeo g = launch_geometry(mode, a.dm, a.batch);
     a.lds_mats = env_on("SPOCK_EMU_NO_LDS_MATS") ? 0 : g.lds_mats;
-    a.team = g.team; a.ex_doubles = g.ex_doubles;
+    a.team = g.team; a.team_reg = g.team_reg; a.ex_doubles = g.ex_doubles;
     const int thr = g.threads, gx = g.grid_x;
     if (thr > 512) return 9;
     switch (mode) {

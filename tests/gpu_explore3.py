@@ -16,9 +16,12 @@ for B in (1, 64):
     print(f"B={B}", {k: round(v[0] * 1e3, 1) for k, v in prof.items() if v[1]})
     for ki, name in enumerate(("sub_a", "crown", "sub_b")):
         st = out[ki].astype(np.int64)
-        n = int(np.count_nonzero(st[:, 1]))
+        n = int(np.count_nonzero(st[:40, 1]))
         cyc = np.diff(st[:n, 0]); wall = np.diff(st[:n, 1]) * 10.0   # ns
         tot_c = st[n - 1, 0] - st[0, 0]; tot_w = (st[n - 1, 1] - st[0, 1]) * 10.0
         print(f"  {name}: {n} stamps, total {tot_w/1e3:.2f} us, {tot_c} cycles -> {tot_c/max(tot_w,1)*1e3:.0f} MHz")
         print("    ns per segment:", [int(x) for x in wall])
+        t0 = st[0, 1]
+        ws = [(int(st[40 + w, 1] - t0) * 10, int(st[50 + w, 1] - t0) * 10) for w in range(8) if st[40 + w, 1]]
+        print("    per-wave (start, end) ns relative to stamp 0:", ws)
     m.close()
