@@ -175,7 +175,19 @@ def main():
             single["ms_to_tol_1e-3_nu5"] = round(r5["solve_ms"], 3)
             single["iterations_to_tol_nu5"] = r5["iterations"]
             m5.close()
+            # the Spock algorithm proper (SuperMann-accelerated CP, SolverOptions(SP, nothing)) on the same convergent tree
+            ms = S.build_model(*specs5, S.SolverOptions(S.SP, None), batch=1, device=local_rank)
+            S.solve_model(ms, np.full(NX, 0.1), tol=1e-3); ms.reset()
+            rs = S.solve_model(ms, np.full(NX, 0.1), tol=1e-3)
+            single["sp_ms_to_tol_1e-3_nu5"] = round(rs["solve_ms"], 3)
+            single["sp_iterations_to_tol_nu5"] = rs["iterations"]
+            single["sp_iterations_per_s"] = round(rs["iterations"] / (rs["solve_ms"] * 1e-3), 1)
+            ms.close()
             if not args.no_cpu_baseline:
+                osp = O.Oracle(flat5, O.SP)
+                t = time.perf_counter(); rosp = osp.solve(np.full(NX, 0.1), tol=1e-3); dtsp = time.perf_counter() - t
+                single["cpu_oracle_sp_ms_to_tol_nu5"] = round(dtsp * 1e3, 1)
+                single["cpu_oracle_sp_iterations_nu5"] = rosp["iterations"]
                 o5 = O.Oracle(flat5, O.CP)
                 t = time.perf_counter(); ro = o5.solve(np.full(NX, 0.1), tol=1e-3); dt5 = time.perf_counter() - t
                 single["cpu_oracle_ms_to_tol_nu5"] = round(dt5 * 1e3, 1)

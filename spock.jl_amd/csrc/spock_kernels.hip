@@ -231,7 +231,6 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
 __global__ void __launch_bounds__(64) spock_mpc_advance_kernel(const MpcArgs a) {
     const int inst = blockIdx.x, r = threadIdx.x;
     const Dims &dm = a.dm;
-    __shared__ double xs[kDynMaxNx];
     const double *z = a.z + (long)inst * a.stride_z;
     double *x0 = a.x0 + (long)inst * dm.nx;
     const int w = a.w_seq[(long)inst * a.steps + a.t];
@@ -243,7 +242,6 @@ __global__ void __launch_bounds__(64) spock_mpc_advance_kernel(const MpcArgs a) 
     if (r < dm.nu) a.u_traj[((long)inst * a.steps + a.t) * dm.nu + r] = z[dm.zu + r];
     __syncthreads();   // every row has read the old x0
     if (r < dm.nx) { x0[r] = xn; a.x_traj[((long)inst * (a.steps + 1) + a.t + 1) * dm.nx + r] = xn; }
-    (void)xs;
 }
 
 int launch_mpc_advance(const MpcArgs &a, void *stream) {
