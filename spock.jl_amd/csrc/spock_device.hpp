@@ -73,6 +73,8 @@ struct DynDims {
     SPK_DEV int ny() const { return ny_; }
 };
 
+constexpr int kStageRegs = 4;   // sweep inputs a thread can hold in registers while the control block is in flight
+
 // Per-thread state that lives across the phases of one kernel (registers on the GPU).
 template <class P>
 struct TState {
@@ -85,6 +87,7 @@ struct TState {
     double ub[P::MAXNU];      // phase A: e_i = Rt^-1 ubar_i       -> u_i
     double dd[P::MAXNU];      // d_i of the Riccati recursion
     double xl[P::MAXD][P::MAXNX];  // leaf children: xbar_j -> x_j
+    double stg[kStageRegs];        // early-issued loads of the sweep inputs (spock_group.hpp)
     // register-resident lane-team sweep (small compile-time shapes): this thread = (node tn_li, matrix row tn_r)
     // and keeps ITS rows of the sweep matrices of its node's stage for the whole kernel
     int tn_li, tn_r, tn_lvl, tn_pos;
@@ -732,17 +735,25 @@ SPK_DEV double mpc_advance_row(const Dims &dm, MatPtr M, const double *z, const 
 // Termination bookkeeping of run_cp! / should_terminate! (cp.jl:54-123, :205-228), run by ONE thread per
 // instance at the start of an iteration (for the previous one) and by the finalize kernel.
 // Returns true when the instance is finished.
-SPK_DEV bool ctl_prologue(Ctl &c, double x1, double x2, double x3, double *hist, int hist_cap, int parity,
+// Snapshot of the control block taken with ONE batch of loads (together with the residual partials), so that the
+// termination logic costs one memory round trip instead of a chain of dependent ones.
+struct CtlSnap { int done, pending, log_mode, alg, max_iter, evals, iter; double tol, r0, r1; };
+SPK_DEV CtlSnap ctl_snapshot(const Ctl &c) {
+    CtlSnap s;
+    s.done = c.done; s.pending = c.pending; s.log_mode = c.log_mode; s.alg = c.alg; s.max_iter = c.max_iter;
+    s.evals = c.evals; s.iter = c.iter; s.tol = c.tol; s.r0 = c.res0[0]; s.r1 = c.res0[1];
+    return s;
+}
+
+SPK_DEV bool ctl_prologue(Ctl &c, const CtlSnap &s, double x1, double x2, double x3, double *hist, int hist_cap, int parity,
                           bool start_next) {
-    // every field is read once into a scalar and written back once where it changed (a struct copy would live in scratch)
-    if (c.done) return true;
-    if (c.pending) {
-        const int log_mode = c.log_mode, alg = c.alg, max_iter = c.max_iter;
-        const double tol = c.tol, r0 = c.res0[0], r1 = c.res0[1];
-        int evals = c.evals, iter = c.iter;
-        const bool log = (log_mode == 2);
+    if (s.done) return true;
+    if (s.pending) {
+        const double tol = s.tol;
+        int evals = s.evals, iter = s.iter;
+        const bool log = (s.log_mode == 2);
         double xi = NAN;
-        if (log) xi = (alg == 1) ? x3 : (x1 > x2 ? x1 : x2);   // cp.jl:83-86 / sp.jl:308
+        if (log) xi = (s.alg == 1) ? x3 : (x1 > x2 ? x1 : x2);   // cp.jl:83-86 / sp.jl:308
         c.xi1 = x1; c.xi2 = x2; c.xi = xi;
         if (hist && evals < hist_cap) {
             double *h = hist + (long)evals * kHistStride;
@@ -750,23 +761,22 @@ SPK_DEV bool ctl_prologue(Ctl &c, double x1, double x2, double x3, double *hist,
         }
         evals += 1;
         c.evals = evals;
-        c.pending = 0;
         bool term;
         if (log) term = (xi <= tol);
         else {
-            const double t1 = tol * r0 > tol ? tol * r0 : tol;   // max(tol*res_0, tol)
-            const double t2 = tol * r1 > tol ? tol * r1 : tol;
+            const double t1 = tol * s.r0 > tol ? tol * s.r0 : tol;   // max(tol*res_0, tol)
+            const double t2 = tol * s.r1 > tol ? tol * s.r1 : tol;
             term = (x1 <= t1 && x2 <= t2);
         }
-        if (r0 == -INFINITY) c.res0[0] = x1;
-        if (r1 == -INFINITY) c.res0[1] = x2;
-        if (x1 != x1 || x2 != x2) { c.done = 1; c.status = 2; c.result_parity = parity; return true; }
-        if (term) { c.done = 1; c.status = 0; c.result_parity = parity; return true; }
+        if (s.r0 == -INFINITY) c.res0[0] = x1;
+        if (s.r1 == -INFINITY) c.res0[1] = x2;
+        if (x1 != x1 || x2 != x2) { c.pending = 0; c.done = 1; c.status = 2; c.result_parity = parity; return true; }
+        if (term) { c.pending = 0; c.done = 1; c.status = 0; c.result_parity = parity; return true; }
         iter += 1;
         c.iter = iter;
-        if (iter >= max_iter) { c.done = 1; c.status = 1; c.result_parity = parity; return true; }
+        if (iter >= s.max_iter) { c.pending = 0; c.done = 1; c.status = 1; c.result_parity = parity; return true; }
     }
-    if (start_next) c.pending = 1;
+    c.pending = start_next ? 1 : 0;
     return false;
 }
 

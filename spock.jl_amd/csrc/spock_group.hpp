@@ -56,35 +56,6 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     };
     stamp();   // 0: entry
 
-    // ---- control: has this instance finished?  (FULL / CROWN also run the pending termination test)
-    if (!(flags & F_NO_CTL)) {
-        if ((MODE == MODE_FULL || MODE == MODE_CROWN || MODE == MODE_FINALIZE) && !(flags & F_SP)) {
-            if (ctl.pending && !ctl.done) {   // workgroup-parallel max over the per-workgroup residual maxima
-                x.each([&](int tid, TState<P> &) {
-                    double mx[3] = {0., 0., 0.};
-                    for (int gg = tid; gg < n_groups; gg += x.nthreads()) {
-                        for (int k = 0; k < 3; ++k) mx[k] = spk_max_nan(mx[k], partials[gg * kPartialStride + k]);
-                    }
-                    x.stash3(tid, mx);
-                });
-                x.reduce3();
-            }
-            x.each([&](int tid, TState<P> &) {
-                if (tid == 0) {
-                    double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
-                    x.flag() = ctl_prologue(ctl, x.red3(0), x.red3(1), x.red3(2), hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
-                }
-            });
-            x.barrier();
-            if (x.flag()) return;
-        } else {
-            if (ctl.done) return;
-        }
-    }
-    if (MODE == MODE_FINALIZE) return;
-    stamp();   // 1: control done
-
-    const double gamma = ctl.gamma, sigma = ctl.sigma;
     const MatPtr M = (MatPtr)a.mats;
     const double *z = a.z_in + (long)inst * a.stride_z;
     const double *v = a.v_in + (long)inst * a.stride_v;
@@ -131,7 +102,70 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // register-resident variant of the team sweep: rows of this thread's node in registers, loaded before phase A so that
     // their latency hides behind it
     const bool team_reg = P::REGROWS && team > 0 && a.team_reg && (team * nl_grp <= x.nthreads());
-    if (team_reg) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s); });
+    if (team_reg && MODE != MODE_FULL) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s); });
+
+    // Every first touch of data another kernel wrote is a cold miss (~1.5-2 us: the writer sat on another XCD).  Issue all
+    // of this kernel's initial loads -- the matrix rows above, the sweep inputs staged here in registers, and the control
+    // block below -- BEFORE waiting for any of them, so that the round trips overlap instead of queueing up.
+    //   crown : c_i / e_i of the crown nodes (cbuf) and q of the subtree roots (qroot)
+    //   SUB_B : d_i of the subtree's nodes (dbuf)
+    const int st_n1 = (MODE == MODE_CROWN) ? nl_grp * nxu : ((MODE == MODE_SUB_B && !crown_blk) ? nl_grp * p.nu() : 0);
+    const int st_n2 = (MODE == MODE_CROWN) ? ngl_grp * p.nx() : 0;
+    const bool staged = team && (st_n1 + st_n2 > 0) && (st_n1 + st_n2 <= kStageRegs * x.nthreads());
+    if (staged) {
+        const double *qg = a.qroot + (long)inst * dm.nsub * dm.nx;
+        const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+        x.each([&](int tid, TState<P> &s) {
+            for (int j = 0; j < kStageRegs; ++j) {
+                const int k = tid + j * x.nthreads();
+                double val = 0.;
+                if (MODE == MODE_CROWN) {
+                    if (k < st_n1) val = cb[k];
+                    else if (k < st_n1 + st_n2) val = qg[k - st_n1];
+                } else if (k < st_n1) {   // element k of ED: local node k / nu sits in the level chunk that contains it
+                    const int li = k / p.nu(), comp = k - li * p.nu();
+                    int lfirst = 0, cnt = 1, l = 0;
+                    while (li >= lfirst + cnt) { lfirst += cnt; cnt *= p.d(); ++l; }
+                    const long gnode = dm.first[root_stage + l] + (long)root_pos * cnt + (li - lfirst);
+                    val = db[gnode * p.nu() + comp];
+                }
+                s.stg[j] = val;
+            }
+        });
+    }
+
+    // ---- control: has this instance finished?  (FULL / CROWN also run the pending termination test)
+    if (!(flags & F_NO_CTL)) {
+        if ((MODE == MODE_FULL || MODE == MODE_CROWN || MODE == MODE_FINALIZE) && !(flags & F_SP)) {
+            // one batch of loads: the control block's fields and this thread's share of the residual partials
+            const CtlSnap snap = ctl_snapshot(ctl);
+            x.each([&](int tid, TState<P> &) {
+                double mx[3] = {0., 0., 0.};
+                for (int gg = tid; gg < n_groups; gg += x.nthreads()) {
+                    for (int k = 0; k < 3; ++k) mx[k] = spk_max_nan(mx[k], partials[gg * kPartialStride + k]);
+                }
+                x.stash3(tid, mx);
+            });
+            if (snap.pending && !snap.done) x.reduce3();   // workgroup-parallel max over the per-workgroup residual maxima
+            x.each([&](int tid, TState<P> &) {
+                if (tid == 0) {
+                    double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
+                    x.flag() = ctl_prologue(ctl, snap, x.red3(0), x.red3(1), x.red3(2), hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
+                }
+            });
+            x.barrier();
+            if (x.flag()) return;
+        } else {
+            if (ctl.done) return;
+        }
+    }
+    if (MODE == MODE_FINALIZE) return;
+    stamp();   // 1: control done
+
+    const double gamma = ctl.gamma, sigma = ctl.sigma;
+    // (whole-tree kernel: loaded after the control section -- its register budget is exhausted and keeping 39 more values
+    //  live across the control code made the spilled build misbehave on the GPU; the split kernels do not spill)
+    if (team_reg && MODE == MODE_FULL) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s); });
 
     // ---- phase A (node-local)
     if ((MODE == MODE_FULL || MODE == MODE_SUB_A) && !(flags & F_NO_ALOCAL)) {
@@ -169,12 +203,20 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
             for (int k = 0; k < l; ++k) { lfirst += cnt; cnt *= d; }
             gfirst = dm.first[root_stage + l] + (long)root_pos * cnt;
         };
-        if (MODE == MODE_CROWN) {   // c_i, e_i of the crown and q of the subtree roots: coalesced copies
+        if (MODE == MODE_CROWN) {   // c_i, e_i of the crown and q of the subtree roots -> LDS
             const double *qg = a.qroot + (long)inst * dm.nsub * dm.nx;
-            x.each([&](int tid, TState<P> &) {
-                for (int k = tid; k < nl_grp * nx; k += nthr) tl.XQ[k] = cb[k];
-                for (int k = tid; k < nl_grp * nu; k += nthr) tl.ED[k] = cb[nl_grp * nx + k];
-                for (int k = tid; k < ngl_grp * nx; k += nthr) tl.XL[k] = qg[k];
+            x.each([&](int tid, TState<P> &s) {
+                if (staged) {   // XQ and ED are adjacent in LDS, exactly like c | e in cbuf
+                    for (int j = 0; j < kStageRegs; ++j) {
+                        const int k = tid + j * nthr;
+                        if (k < st_n1) tl.XQ[k] = s.stg[j];
+                        else if (k < st_n1 + st_n2) tl.XL[k - st_n1] = s.stg[j];
+                    }
+                } else {
+                    for (int k = tid; k < nl_grp * nx; k += nthr) tl.XQ[k] = cb[k];
+                    for (int k = tid; k < nl_grp * nu; k += nthr) tl.ED[k] = cb[nl_grp * nx + k];
+                    for (int k = tid; k < ngl_grp * nx; k += nthr) tl.XL[k] = qg[k];
+                }
             });
         }
         if (MODE != MODE_SUB_B && !(flags & F_DBG_NO_BWD)) {
@@ -211,14 +253,17 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         if (MODE != MODE_SUB_A && !(flags & F_DBG_NO_FWD)) {
             const double *xroot = (MODE == MODE_SUB_B) ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
             const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
-            x.each([&](int tid, TState<P> &) {
+            x.each([&](int tid, TState<P> &s) {
                 if (tid < nx) tl.XQ[tid] = xroot[tid];
-                if (MODE == MODE_SUB_B)
+                if (MODE == MODE_SUB_B && staged) {
+                    for (int j = 0; j < kStageRegs; ++j) { const int k = tid + j * nthr; if (k < st_n1) tl.ED[k] = s.stg[j]; }
+                } else if (MODE == MODE_SUB_B) {
                     for (int l = 0; l <= stages - 2; ++l) {
                         int lfirst, cnt; long gfirst;
                         level_geo(l, lfirst, cnt, gfirst);
                         for (int k = tid; k < cnt * nu; k += nthr) tl.ED[lfirst * nu + k] = db[gfirst * nu + k];
                     }
+                }
             });
             x.barrier();
             stamp();   // forward inputs in LDS
