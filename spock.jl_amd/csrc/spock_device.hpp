@@ -28,6 +28,11 @@
 #define SPK_DEV __device__ __forceinline__
 #define SPK_UNROLL _Pragma("unroll P::UNR")
 #endif
+#ifdef SPOCK_HOST_EMU
+#define SPK_UNROLL4
+#else
+#define SPK_UNROLL4 _Pragma("unroll 4")   // run-time trip counts: keep four independent loads in flight
+#endif
 
 namespace spock {
 
@@ -53,24 +58,35 @@ struct StaticDims {
     static constexpr int MAXNX = NX, MAXNU = NU, MAXD = D, MAXNY = NY, MAXM = NY + 2 * D, UNR = 128;
     static constexpr bool DIAG = (CM == CM_SHARED_DIAG), SHARED = (CM != CM_GENERAL);
     static constexpr bool REGROWS = (NX <= 8 && NU <= 8);   // register-resident team sweep available
+    static constexpr bool TEAMLOCAL = false;
     SPK_DEV explicit StaticDims(const Dims &) {}
     SPK_DEV constexpr int nx() const { return NX; }
     SPK_DEV constexpr int nu() const { return NU; }
     SPK_DEV constexpr int d() const { return D; }
     SPK_DEV constexpr int ny() const { return NY; }
 };
-template <int CM>
+// TL: lane-team node-local phases (spock_team_local.hpp) instead of the per-thread ones: no per-thread vectors at all
+template <int CM, bool TL = false>
 struct DynDims {
-    static constexpr int MAXNX = kDynMaxNx, MAXNU = kDynMaxNu, MAXD = kDynMaxD, MAXNY = kDynMaxNy,
-                         MAXM = kDynMaxNy + 2 * kDynMaxD, UNR = 1;
+    static constexpr int MAXNX = TL ? 1 : kDynMaxNx, MAXNU = TL ? 1 : kDynMaxNu, MAXD = kDynMaxD, MAXNY = TL ? 1 : kDynMaxNy,
+                         MAXM = TL ? 1 : kDynMaxNy + 2 * kDynMaxD, UNR = 1;
     static constexpr bool DIAG = (CM == CM_SHARED_DIAG), SHARED = (CM != CM_GENERAL);
-    static constexpr bool REGROWS = false;
+    static constexpr bool REGROWS = false, TEAMLOCAL = TL;
     int nx_, nu_, d_, ny_;
     SPK_DEV explicit DynDims(const Dims &dm) : nx_(dm.nx), nu_(dm.nu), d_(dm.d), ny_(dm.ny) {}
     SPK_DEV int nx() const { return nx_; }
     SPK_DEV int nu() const { return nu_; }
     SPK_DEV int d() const { return d_; }
     SPK_DEV int ny() const { return ny_; }
+};
+
+// lane-team node-local phases (spock_team_local.hpp): per-lane registers carried from part 1 to part 2 of a phase
+template <class P>
+struct TLReg {
+    double xb, ub;                        // A: xbar_r, ubar_r         B: x_i[r] - z (dz), see below
+    double wx, dzx, wu, dzu, wy, dzy;     // B: w = 2 zbar - z and dz = zbar - z on x_i[r], u_i[r], y_i[r]
+    double t3[P::MAXD], l3[P::MAXD], t4[P::MAXD], l4[P::MAXD];       // child blocks: pre-prox value / (L dz)
+    double t11[P::MAXD], l11[P::MAXD], t14[P::MAXD], wl[P::MAXD], dl[P::MAXD];   // leaf blocks
 };
 
 constexpr int kStageRegs = 4;   // sweep inputs a thread can hold in registers while the control block is in flight
@@ -88,6 +104,8 @@ struct TState {
     double dd[P::MAXNU];      // d_i of the Riccati recursion
     double xl[P::MAXD][P::MAXNX];  // leaf children: xbar_j -> x_j
     double stg[kStageRegs];        // early-issued loads of the sweep inputs (spock_group.hpp)
+    TLReg<P> tlr;                  // lane-team local phases
+    double mx3[3];                 // residual maxima accumulated over the rounds of the lane-team phase B
     // register-resident lane-team sweep (small compile-time shapes): this thread = (node tn_li, matrix row tn_r)
     // and keeps ITS rows of the sweep matrices of its node's stage for the whole kernel
     int tn_li, tn_r, tn_lvl, tn_pos;
@@ -353,8 +371,8 @@ SPK_DEV void bwd_level_team(const P &p, const Dims &dm, MPT SW, int lvl_first, i
             const double *qc = kids_gleaf ? L.XL + (pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
             const MPT W = SW + dm.sw_oW + c * nx * nx;
             const MPT V = SW + dm.sw_oV + c * nu * nx;
-            if (r < nx) { SPK_UNROLL for (int k = 0; k < nx; ++k) q += W[r + k * nx] * qc[k]; }
-            if (r < nu) { SPK_UNROLL for (int k = 0; k < nx; ++k) dd -= V[r + k * nu] * qc[k]; }
+            if (r < nx) { SPK_UNROLL4 for (int k = 0; k < nx; ++k) q += W[r + k * nx] * qc[k]; }
+            if (r < nu) { SPK_UNROLL4 for (int k = 0; k < nx; ++k) dd -= V[r + k * nu] * qc[k]; }
         }
         if (r < nx) L.XQ[li * nx + r] = q;
         if (r < nu) L.ED[li * nu + r] = dd;
@@ -374,8 +392,8 @@ SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
                 const MPT Bw = Bm + slot_event(c, d) * nx * nu;
                 const MPT Ab = SW + dm.sw_oABK + c * nx * nx;
                 double a = 0., b2 = 0.;
-                SPK_UNROLL for (int k = 0; k < nx; ++k) a += Ab[r + k * nx] * xi[k];
-                SPK_UNROLL for (int k = 0; k < nu; ++k) b2 += Bw[r + k * nx] * di[k];
+                SPK_UNROLL4 for (int k = 0; k < nx; ++k) a += Ab[r + k * nx] * xi[k];
+                SPK_UNROLL4 for (int k = 0; k < nu; ++k) b2 += Bw[r + k * nx] * di[k];
                 double *dst = kids_gleaf ? L.XL + (pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
                 dst[r] = a + b2;
             }
@@ -383,7 +401,7 @@ SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
         if (r < nu) {
             const MPT Kt = SW + dm.sw_oK;
             double a = 0.;
-            SPK_UNROLL for (int k = 0; k < nx; ++k) a += Kt[r + k * nu] * xi[k];
+            SPK_UNROLL4 for (int k = 0; k < nx; ++k) a += Kt[r + k * nu] * xi[k];
             L.UL[li * nu + r] = a + di[r];
         }
     }

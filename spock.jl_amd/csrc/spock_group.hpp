@@ -21,6 +21,7 @@
 //         workgroup nsub: phase B on the crown; residual maxima per workgroup
 #pragma once
 #include "spock_device.hpp"
+#include "spock_team_local.hpp"
 
 namespace spock {
 
@@ -168,7 +169,34 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     if (team_reg && MODE == MODE_FULL) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s); });
 
     // ---- phase A (node-local)
-    if ((MODE == MODE_FULL || MODE == MODE_SUB_A) && !(flags & F_NO_ALOCAL)) {
+    // lane-team node-local phases (large nx / nu, diagonal costs): T lanes per node, team scratch behind the sweep vectors
+    const bool team_local = P::TEAMLOCAL;
+    const int TT = a.team > 0 ? a.team : 8, nteams = x.nthreads() / TT;
+    double *tscr = tl.XL + ngl_grp * p.nx();
+    const int tscr_stride = team_scratch_doubles(p.nu(), p.ny() + 2 * p.d(), p.d(), TT);
+    if (team_local && (MODE == MODE_FULL || MODE == MODE_SUB_A) && !(flags & F_NO_ALOCAL)) {
+        for (int base = 0; base < nl_grp; base += nteams) {
+            x.each([&](int tid, TState<P> &s) {
+                const int tm = tid / TT, r = tid - tm * TT;
+                if (tm >= nteams) return;
+                const TeamNode tn = team_node(dm, p.d(), base + tm, nl_grp, root_stage, root_pos, stages, crown);
+                ta_p1(p, dm, M, z, v, zo, tn, r, TT, tscr + tm * tscr_stride, crown_blk ? nullptr : tl.XL, gamma, flags, s.tlr);
+            });
+            x.barrier();
+            if (!(flags & F_RAW_LT))
+                x.each([&](int tid, TState<P> &s) {
+                    const int tm = tid / TT, r = tid - tm * TT;
+                    if (tm >= nteams) return;
+                    const TeamNode tn = team_node(dm, p.d(), base + tm, nl_grp, root_stage, root_pos, stages, crown);
+                    double *cq = crown_blk ? cb + tn.li * p.nx() : tl.XQ + tn.li * p.nx();
+                    double *ce = crown_blk ? cb + nl_grp * p.nx() + tn.li * p.nu() : tl.ED + tn.li * p.nu();
+                    ta_p2(p, dm, M, zo, tn, r, TT, tscr + tm * tscr_stride, cq, ce, s.tlr);
+                });
+            x.barrier();
+        }
+        if (crown_blk) return;
+    }
+    if (!team_local && (MODE == MODE_FULL || MODE == MODE_SUB_A) && !(flags & F_NO_ALOCAL)) {
         x.each([&](int, TState<P> &s) { if (s.active) a_local(p, dm, M, z, v, zo, s, gamma, flags); });
         if (team && !crown_blk) {   // hand c_i, e_i and the leaves' q = -xbar over to the lane teams
             x.each([&](int tid, TState<P> &s) {
@@ -292,7 +320,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 }
                 const long gl_first = dm.first[root_stage + stages - 1] + (long)root_pos * ngl_grp;
                 for (int k = tid; k < ngl_grp * nx; k += nthr) zo[dm.zx + gl_first * nx + k] = tl.XL[k];
-                if (s.active) {
+                if (s.active && !team_local) {
                     for (int k = 0; k < nx; ++k) s.xb[k] = tl.XQ[tid * nx + k];
                     for (int k = 0; k < nu; ++k) s.ub[k] = tl.UL[tid * nu + k];
                     if (s.kids_leaf)
@@ -366,11 +394,36 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         ps.inv_gamma_neg = -1. / gamma;
         ps.want_xi = (ctl.log_mode == 2 && ctl.alg == 1);
         const unsigned bflags = crown_blk ? (flags | F_NO_SWEEP) : flags;   // the crown's x, u come from zbar
-        x.each([&](int tid, TState<P> &s) {
-            double mx[3] = {0., 0., 0.};
-            if (s.active) b_local(p, dm, M, z, v, zo, vo, s, ps, bflags, mx);
-            x.stash3(tid, mx);
-        });
+        if (team_local) {
+            const bool from_zb = (bflags & F_NO_SWEEP) != 0;
+            x.each([&](int, TState<P> &s) { s.mx3[0] = s.mx3[1] = s.mx3[2] = 0.; });
+            for (int base = 0; base < nl_grp; base += nteams) {
+                x.each([&](int tid, TState<P> &s) {
+                    const int tm = tid / TT, r = tid - tm * TT;
+                    if (tm >= nteams) return;
+                    const TeamNode tn = team_node(dm, p.d(), base + tm, nl_grp, root_stage, root_pos, stages, crown);
+                    const double *xs = from_zb ? zo + dm.zx + (long)tn.node * p.nx() : tl.XQ + tn.li * p.nx();
+                    const double *us = from_zb ? zo + dm.zu + (long)tn.node * p.nu() : tl.UL + tn.li * p.nu();
+                    const double *xl = from_zb ? zo + dm.zx + (long)tn.c0 * p.nx() : tl.XL + (tn.pos * p.d()) * p.nx();
+                    tb_p1(p, dm, M, z, v, zo, tn, r, TT, tscr + tm * tscr_stride, xs, us, xl, p.nx(), ps, bflags, s.tlr);
+                });
+                x.barrier();
+                x.each([&](int tid, TState<P> &s) {
+                    const int tm = tid / TT, r = tid - tm * TT;
+                    if (tm >= nteams) return;
+                    const TeamNode tn = team_node(dm, p.d(), base + tm, nl_grp, root_stage, root_pos, stages, crown);
+                    tb_p2(p, dm, M, z, v, zo, vo, tn, r, TT, tscr + tm * tscr_stride, ps, bflags, s.tlr, s.mx3);
+                });
+                x.barrier();
+            }
+            x.each([&](int tid, TState<P> &s) { x.stash3(tid, s.mx3); });
+        } else {
+            x.each([&](int tid, TState<P> &s) {
+                double mx[3] = {0., 0., 0.};
+                if (s.active) b_local(p, dm, M, z, v, zo, vo, s, ps, bflags, mx);
+                x.stash3(tid, mx);
+            });
+        }
         const int slot = (MODE == MODE_SUB_B) ? g : 0;
         x.reduce3();
         x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + tid] = x.red3(tid); });

@@ -130,16 +130,22 @@ int group_threads(int d, int stages) { return stages < 2 ? 0 : (ipow(d, stages -
 // non-leaf node and nx doubles of LDS per thread for the q / x exchange of the S1 sweeps.
 int choose_split_stage(int N, int d, int nx) {
     int max_thr = 512;
-    const int lds_thr = (64 * 1024 / 8) / (nx > 0 ? nx : 1);
+    const int lds_thr = (144 * 1024 / 8) / (nx > 0 ? nx : 1);
     if (lds_thr < max_thr) max_thr = lds_thr;
-    if (group_threads(d, N) <= max_thr) return 0;
+    // one workgroup for the whole tree only while the tree is small: beyond ~128 non-leaf nodes the subtree kernels on
+    // many CUs win even for a single instance (measured N = 10, nx = 5: 54 us whole-tree vs 42 us split)
+    if (group_threads(d, N) <= (max_thr < 128 ? max_thr : 128)) return 0;
     int t0 = (N - 1) / 2;
     while (t0 < N - 2 && group_threads(d, N - t0) > max_thr) ++t0;
     if (group_threads(d, N - t0) > max_thr || group_threads(d, t0 + 1) > max_thr) return -1;
     return t0;
 }
 
-// Threads, grid, LDS carve-up of one launch.  Team sweeps (spock_device.hpp) are used whenever their LDS vectors fit.
+bool team_local_applies(const Dims &dm) {
+    if (std::getenv("SPOCK_AMD_NO_TEAM_LOCAL")) return false;
+    return (dm.nx > 8 || dm.nu > 8) && dm.diag_costs && dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1 && !dm.risk_has_soc;
+}
+
 LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     LaunchGeo g;
     const int d = dm.d, nx = dm.nx, nu = dm.nu;
@@ -165,7 +171,8 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     int T = 8;
     while (T < nx || T < nu) T *= 2;
     const long mats_bytes = ((long)(max_stages - 1) * dm.sw_stride + (long)d * nx * nu) * 8;
-    const long budget = 60 * 1024, tail = (4 + 128) * 8;   // reduction scratch + flag + 64 diagnostic clock stamps
+    // 160 KiB of LDS per CU on MI355X; the launcher raises the dynamic-LDS limit of the kernel when more than 64 KiB is used
+    const long budget = 144 * 1024, tail = (4 + 128) * 8;   // reduction scratch + flag + 64 diagnostic clock stamps
     // Lane teams pay off when a node's mat-vecs are big (measured on MI355X: nx = nu = 20, N = 10: 3058 -> 561 us per
     // iteration).  For the small compile-time shapes (nx <= 8) one thread per node with the vectors in registers and
     // the matrices in SGPRs is as fast per level and keeps workgroups at one wave, which the batched regime needs
@@ -183,7 +190,15 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     if (mode != MODE_FINALIZE && want_reg && team_doubles * 8 + tail <= budget) { g.team = T; g.team_reg = 1; }
     else g.team = (mode != MODE_FINALIZE && want_team && T <= 64 && team_doubles * 8 + tail <= budget) ? T : 0;
     g.threads = r64(nl);
-    if (g.team_reg) g.threads = r64(g.team * nl);
+    g.team_local = 0;
+    if (g.team && !g.team_reg && mode != MODE_FINALIZE && team_local_applies(dm)) {
+        // lane-team node-local phases: 256 threads = 256 / T teams, each with its scratch behind the sweep vectors
+        const int thr = 256, nteams = thr / g.team;
+        const long scr = (long)nteams * ((dm.ny + 2 * d) + nu + (2 + 2 * d) * g.team);
+        if ((team_doubles + scr) * 8 + tail <= budget) { g.team_local = 1; team_doubles += scr; g.threads = thr; }
+    }
+    if (g.team_local) {}
+    else if (g.team_reg) g.threads = r64(g.team * nl);
     else if (g.team) {
         int want = r64(g.team * widest);
         if (want > 512) want = 512;
@@ -250,7 +265,7 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
     if (t0 < 0) { unsupported = true; return "tree does not fit the two-level subtree tiling"; }
     if (t0 > 0) {
         if (t0 > N - 2) return "split_stage must leave subtrees of at least two stages";
-        const int lim = (64 * 1024 / 8) / nx < 512 ? (64 * 1024 / 8) / nx : 512;
+        const int lim = (144 * 1024 / 8) / nx < 512 ? (144 * 1024 / 8) / nx : 512;
         if (group_threads(d, N - t0) > lim || group_threads(d, t0 + 1) > lim) { unsupported = true; return "split_stage gives groups larger than one workgroup"; }
     }
     dm.t0 = t0;

@@ -129,6 +129,7 @@ struct SpArgs {
     int batch;
     long nr;
     int op;
+    int team;                  // lanes per node of the lane-team LOP (large nx), else 0
 };
 
 enum SpOp { SP_FLAT1 = 1, SP_FLAT2, SP_FLAT3, SP_FLAT4, SP_FLAT5, SP_LOP_R, SP_LOP_RT, SP_LOP_DP,
@@ -155,7 +156,8 @@ struct BuildProducts {
 std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported);
 int choose_split_stage(int N, int d, int nx);
 // launch geometry shared by the GPU launcher and the emulation harness
-struct LaunchGeo { int threads, grid_x, team, team_reg, lds_mats, ex_doubles; size_t lds_bytes; };
+struct LaunchGeo { int threads, grid_x, team, team_reg, team_local, lds_mats, ex_doubles; size_t lds_bytes; };
+bool team_local_applies(const Dims &dm);   // lane-team node-local phases: large nx / nu, shared diagonal costs, no SOC risk cone
 LaunchGeo launch_geometry(int mode, const Dims &dm, int batch);
 int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tree with `stages` stages
 

@@ -9,6 +9,7 @@
 
 #include "spock_group.hpp"
 #include "spock_sp.hpp"
+#include "spock_team_local.hpp"
 
 namespace spock {
 
@@ -78,8 +79,22 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     bool stage = g.lds_mats && ((long)a.batch * g.grid_x >= 1024 || g.team);
     if (const char *e = std::getenv("SPOCK_AMD_LDS_MATS")) stage = g.lds_mats && e[0] == '1';
     a.lds_mats = stage ? 1 : 0; a.team = g.team; a.team_reg = g.team_reg; a.ex_doubles = g.ex_doubles;
+    if (P::TEAMLOCAL && !g.team_local && mode != MODE_FINALIZE) return (int)hipErrorInvalidConfiguration;
     const size_t lds = g.lds_bytes;   // sized for the staged matrices either way
     const dim3 grid(g.grid_x, a.batch), block(g.threads);
+    if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: raise it once per kernel (160 KiB per CU on MI355X)
+        static bool raised[5] = {false, false, false, false, false};
+        if (!raised[mode]) {
+            const void *fn = mode == MODE_FULL ? (const void *)spock_group_kernel<P, MODE_FULL>
+                           : mode == MODE_SUB_A ? (const void *)spock_group_kernel<P, MODE_SUB_A>
+                           : mode == MODE_CROWN ? (const void *)spock_group_kernel<P, MODE_CROWN>
+                           : mode == MODE_SUB_B ? (const void *)spock_group_kernel<P, MODE_SUB_B>
+                                                : (const void *)spock_group_kernel<P, MODE_FINALIZE>;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised[mode] = true;
+        }
+    }
     switch (mode) {
         case MODE_FULL: hipLaunchKernelGGL((spock_group_kernel<P, MODE_FULL>), grid, block, lds, st, a); break;
         case MODE_SUB_A: hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_A>), grid, block, lds, st, a); break;
@@ -111,6 +126,7 @@ int launch_group(int mode, const KArgs &a, void *stream) {
                              : launch_variant<StaticDims<a_, b_, c_, e_, 0>>(mode, a, st);
     SPOCK_STATIC_SHAPES(X)
 #undef X
+    if (cm == 2 && launch_geometry(mode == MODE_FINALIZE ? MODE_CROWN : mode, dm, a.batch).team_local) return launch_variant<DynDims<2, true>>(mode, a, st);
     return cm == 2 ? launch_variant<DynDims<2>>(mode, a, st) : cm == 1 ? launch_variant<DynDims<1>>(mode, a, st) : launch_variant<DynDims<0>>(mode, a, st);
 }
 
@@ -187,7 +203,14 @@ __global__ void __launch_bounds__(512) spock_sp_lop_kernel(const SpArgs a) {
     else if (a.op == SP_LOP_RT) { A = a.RW + o; B = a.RW + o; B2 = a.D + o; }
     else { B = a.DP + o; }
     double acc[4] = {0., 0., 0., 0.};
-    if (s.active) lop_local(p, dm, (MatPtr)a.mats, A, B, B2, s, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
+    if (P::TEAMLOCAL) {   // T lanes per node, no exchange between lanes: rounds over the group's nodes
+        const int T = a.team, nteams = blockDim.x / T, tm = threadIdx.x / T, r = threadIdx.x - tm * T;
+        const int stages = crown ? dm.t0 + 1 : (split ? dm.sub_stages : dm.N), nl_grp = group_threads_dev(p.d(), stages);
+        for (int li = tm; li < nl_grp && tm < nteams; li += nteams) {
+            const TeamNode tn = team_node(dm, p.d(), li, nl_grp, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0, stages, crown);
+            tlop(p, dm, (MatPtr)a.mats, A, B, B2, tn, r, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
+        }
+    } else if (s.active) lop_local(p, dm, (MatPtr)a.mats, A, B, B2, s, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
     double mx[2] = {acc[2], acc[3]};
     block_reduce<2, false>(acc, red);
     __syncthreads();
@@ -250,11 +273,14 @@ int launch_mpc_advance(const MpcArgs &a, void *stream) {
 }
 
 template <class P>
-static int launch_lop(const SpArgs &a, hipStream_t st) {
-    const Dims &dm = a.dm;
+static int launch_lop(const SpArgs &a_in, hipStream_t st) {
+    const Dims &dm = a_in.dm;
     const int sub_thr = group_threads(dm.d, dm.sub_stages), crown_thr = group_threads(dm.d, dm.t0 + 1);
-    const int nthr = dm.t0 > 0 ? (sub_thr > crown_thr ? sub_thr : crown_thr) : group_threads(dm.d, dm.N);
-    hipLaunchKernelGGL((spock_sp_lop_kernel<P>), dim3(sp_lop_blocks(dm), a.batch), dim3(round64(nthr)), 0, st, a);
+    int nthr = round64(dm.t0 > 0 ? (sub_thr > crown_thr ? sub_thr : crown_thr) : group_threads(dm.d, dm.N));
+    SpArgs a = a_in;
+    a.team = 0;
+    if (P::TEAMLOCAL) { a.team = 8; while (a.team < dm.nx || a.team < dm.nu) a.team *= 2; nthr = 256; }
+    hipLaunchKernelGGL((spock_sp_lop_kernel<P>), dim3(sp_lop_blocks(dm), a.batch), dim3(nthr), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -277,6 +303,7 @@ int launch_sp(const SpArgs &a, void *stream) {
              : cm == 1 ? launch_lop<StaticDims<a_, b_, c_, e_, 1>>(a, st) : launch_lop<StaticDims<a_, b_, c_, e_, 0>>(a, st);
     SPOCK_STATIC_SHAPES(X)
 #undef X
+    if (cm == 2 && team_local_applies(dm)) return launch_lop<DynDims<2, true>>(a, st);
     return cm == 2 ? launch_lop<DynDims<2>>(a, st) : cm == 1 ? launch_lop<DynDims<1>>(a, st) : launch_lop<DynDims<0>>(a, st);
 }
 

@@ -16,6 +16,7 @@
 
 #include "../../spock.jl_amd/csrc/spock_group.hpp"
 #include "../../spock.jl_amd/csrc/spock_sp.hpp"
+#include "../../spock.jl_amd/csrc/spock_team_local.hpp"
 #include "../../spock.jl_amd/csrc/spock_rt.hpp"
 
 namespace spock {
@@ -102,6 +103,7 @@ int launch_group(int mode, const KArgs &a, void *) {
         SPOCK_STATIC_SHAPES(X)
 #undef X
     }
+    if (cm == 2 && launch_geometry(mode == MODE_FINALIZE ? MODE_CROWN : mode, dm, a.batch).team_local) return launch_variant<DynDims<2, true>>(mode, a);
     return cm == 2 ? launch_variant<DynDims<2>>(mode, a) : cm == 1 ? launch_variant<DynDims<1>>(mode, a) : launch_variant<DynDims<0>>(mode, a);
 }
 
@@ -128,6 +130,18 @@ static int emu_lop(const SpArgs &a) {
             else if (a.op == SP_LOP_RT) { A = a.RW + o; B = a.RW + o; B2 = a.D + o; }
             else { B = a.DP + o; }
             double tot[4] = {0., 0., 0., 0.};
+            if (P::TEAMLOCAL) {
+                int T = 8; while (T < dm.nx || T < dm.nu) T *= 2;
+                const int stages = crown ? dm.t0 + 1 : (split ? dm.sub_stages : dm.N), nl_grp = group_threads(dm.d, stages);
+                for (int li = 0; li < nl_grp; ++li)
+                    for (int r = 0; r < T; ++r) {
+                        const TeamNode tn = team_node(dm, p.d(), li, nl_grp, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0, stages, crown);
+                        double acc[4] = {0., 0., 0., 0.};
+                        tlop(p, dm, (MatPtr)a.mats, A, B, B2, tn, r, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
+                        tot[0] += acc[0]; tot[1] += acc[1];
+                        tot[2] = spk_max_nan(tot[2], acc[2]); tot[3] = spk_max_nan(tot[3], acc[3]);
+                    }
+            } else
             for (int tid = 0; tid < nthr; ++tid) {
                 TState<P> s;
                 init_geometry(p, dm, tid, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0,
@@ -186,6 +200,7 @@ int launch_sp(const SpArgs &a, void *) {
         SPOCK_STATIC_SHAPES(X)
 #undef X
     }
+    if (cm == 2 && team_local_applies(dm)) return emu_lop<DynDims<2, true>>(a);
     return cm == 2 ? emu_lop<DynDims<2>>(a) : cm == 1 ? emu_lop<DynDims<1>>(a) : emu_lop<DynDims<0>>(a);
 }
 
