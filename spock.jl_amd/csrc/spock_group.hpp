@@ -57,6 +57,35 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     };
     stamp();   // 0: entry
 
+    // ---- control: has this instance finished?  (FULL / CROWN also run the pending termination test)
+    if (!(flags & F_NO_CTL)) {
+        if ((MODE == MODE_FULL || MODE == MODE_CROWN || MODE == MODE_FINALIZE) && !(flags & F_SP)) {
+            // one batch of loads: the control block's fields and this thread's share of the residual partials
+            const CtlSnap snap = ctl_snapshot(ctl);
+            x.each([&](int tid, TState<P> &) {
+                double mx[3] = {0., 0., 0.};
+                for (int gg = tid; gg < n_groups; gg += x.nthreads()) {
+                    for (int k = 0; k < 3; ++k) mx[k] = spk_max_nan(mx[k], partials[gg * kPartialStride + k]);
+                }
+                x.stash3(tid, mx);
+            });
+            if (snap.pending && !snap.done) x.reduce3();   // workgroup-parallel max over the per-workgroup residual maxima
+            x.each([&](int tid, TState<P> &) {
+                if (tid == 0) {
+                    double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
+                    x.flag() = ctl_prologue(ctl, snap, x.red3(0), x.red3(1), x.red3(2), hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
+                }
+            });
+            x.barrier();
+            if (x.flag()) return;
+        } else {
+            if (ctl.done) return;
+        }
+    }
+    if (MODE == MODE_FINALIZE) return;
+    stamp();   // 1: control done
+
+
     const MatPtr M = (MatPtr)a.mats;
     const double *z = a.z_in + (long)inst * a.stride_z;
     const double *v = a.v_in + (long)inst * a.stride_v;
@@ -103,11 +132,12 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // register-resident variant of the team sweep: rows of this thread's node in registers, loaded before phase A so that
     // their latency hides behind it
     const bool team_reg = P::REGROWS && team > 0 && a.team_reg && (team * nl_grp <= x.nthreads());
-    if (team_reg && MODE != MODE_FULL) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s); });
+    if (team_reg) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s); });
 
-    // Every first touch of data another kernel wrote is a cold miss (~1.5-2 us: the writer sat on another XCD).  Issue all
-    // of this kernel's initial loads -- the matrix rows above, the sweep inputs staged here in registers, and the control
-    // block below -- BEFORE waiting for any of them, so that the round trips overlap instead of queueing up.
+    // Every first touch of data another kernel wrote is a cold miss (~1.5-2 us: the writer sat on another XCD).  Issue the
+    // matrix-row loads above and the sweep inputs staged here in registers back to back, before waiting for any of them.
+    // (Hoisting them above the control section as well was tried: no measurable gain, and keeping that much state live
+    // across it produced wrong iterates on the GPU in the 512-thread crown -- the control section stays first.)
     //   crown : c_i / e_i of the crown nodes (cbuf) and q of the subtree roots (qroot)
     //   SUB_B : d_i of the subtree's nodes (dbuf)
     const int st_n1 = (MODE == MODE_CROWN) ? nl_grp * nxu : ((MODE == MODE_SUB_B && !crown_blk) ? nl_grp * p.nu() : 0);
@@ -135,38 +165,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         });
     }
 
-    // ---- control: has this instance finished?  (FULL / CROWN also run the pending termination test)
-    if (!(flags & F_NO_CTL)) {
-        if ((MODE == MODE_FULL || MODE == MODE_CROWN || MODE == MODE_FINALIZE) && !(flags & F_SP)) {
-            // one batch of loads: the control block's fields and this thread's share of the residual partials
-            const CtlSnap snap = ctl_snapshot(ctl);
-            x.each([&](int tid, TState<P> &) {
-                double mx[3] = {0., 0., 0.};
-                for (int gg = tid; gg < n_groups; gg += x.nthreads()) {
-                    for (int k = 0; k < 3; ++k) mx[k] = spk_max_nan(mx[k], partials[gg * kPartialStride + k]);
-                }
-                x.stash3(tid, mx);
-            });
-            if (snap.pending && !snap.done) x.reduce3();   // workgroup-parallel max over the per-workgroup residual maxima
-            x.each([&](int tid, TState<P> &) {
-                if (tid == 0) {
-                    double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
-                    x.flag() = ctl_prologue(ctl, snap, x.red3(0), x.red3(1), x.red3(2), hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE) ? 1 : 0;
-                }
-            });
-            x.barrier();
-            if (x.flag()) return;
-        } else {
-            if (ctl.done) return;
-        }
-    }
-    if (MODE == MODE_FINALIZE) return;
-    stamp();   // 1: control done
-
     const double gamma = ctl.gamma, sigma = ctl.sigma;
-    // (whole-tree kernel: loaded after the control section -- its register budget is exhausted and keeping 39 more values
-    //  live across the control code made the spilled build misbehave on the GPU; the split kernels do not spill)
-    if (team_reg && MODE == MODE_FULL) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s); });
 
     // ---- phase A (node-local)
     // lane-team node-local phases (large nx / nu, diagonal costs): T lanes per node, team scratch behind the sweep vectors

@@ -228,6 +228,39 @@ def test_determinism_and_batch(S, O):
     m.close()
 
 
+@pytest.mark.parametrize("nu", [5, 2])
+def test_full_size_cfg2_iterates_match_oracle(S, O, nu):
+    """BASELINE.json config 2 at full size (4096 leaves): the launch geometry used there (64 subtrees, 512-thread crown with
+    the register-resident lane-team sweep) is not reached by the small cases, so the iterates of a fixed number of CP
+    iterations -- and, for the convergent nu = 5 tree, the whole solve -- are compared with the oracle directly."""
+    specs = S.get_server_heat_specs(13, 5, 2, nu=nu)
+    flat = S.flatten_problem(*specs)
+    x0 = np.full(5, 0.1)
+    m = S.build_model(*specs, max_iter=60)
+    o = O.Oracle(flat, O.CP)
+    r = S.solve_model(m, x0, tol=1e-3)
+    ro = o.solve(x0, tol=1e-3, max_iter=60, history=100)
+    h = m.history()
+    assert r["iterations"] == ro["iterations"] == 60
+    assert np.max(np.abs(h["xi1"] - ro["hist_xi1"]) / ro["hist_xi1"]) <= 1e-9
+    assert np.max(np.abs(h["xi2"] - ro["hist_xi2"]) / ro["hist_xi2"]) <= 1e-9
+    assert relerr(m.solver_state.z, o.z) <= 1e-9 and relerr(m.solver_state.v, o.v) <= 1e-9
+    m.close()
+    if nu == 5:
+        m = S.build_model(*specs)
+        o = O.Oracle(flat, O.CP)
+        r = S.solve_model(m, x0, tol=1e-3); ro = o.solve(x0, tol=1e-3)
+        assert (r["iterations"], r["status"]) == (ro["iterations"], ro["status"]) == (442, 0)
+        assert relerr(m.solver_state.z, o.z) <= 1e-8
+        # batched instances take the other launch geometry (LDS-staged matrices, one wave per subtree)
+        mb = S.build_model(*specs, batch=24, max_iter=40)
+        xb = 0.1 * (1 + 0.01 * np.arange(24))[:, None] * np.ones((24, 5))
+        S.solve_model(mb, xb, tol=0.0)
+        ob = O.Oracle(flat, O.CP); ob.solve(xb[17], tol=0.0, max_iter=40)
+        assert relerr(mb.solver_state.z[17], ob.z) <= 1e-9
+        m.close(); mb.close()
+
+
 def test_full_size_cfg2_properties(S):
     """BASELINE.json config 2 (4096 leaves, reference N=13, nx=5): nu=5 (reference-faithful) and nu=2.
     Size-independent checks: adjointness, S1/S2 idempotence, dynamics feasibility of the iterate."""
