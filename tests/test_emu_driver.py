@@ -272,6 +272,78 @@ def test_emulated_closed_form_L_norm(S, O, emu):
     m.close()
 
 
+def _variant_specs(S, name):
+    """Problem variants that reach the less-travelled kernel paths."""
+    rng = np.random.default_rng(42)
+    if name == "per_node_dense_costs":          # CM_GENERAL, compile-time shape (5, 2)
+        tree, cost, dyn, rms, con = S.get_server_heat_specs(5, 5, 2, nu=2)
+        def spd(n, k):
+            a = rng.standard_normal((n, n)); return 0.05 * (a @ a.T) / n + np.eye(n) * (0.05 + 0.01 * (k % 3))
+        cost = S.Cost([spd(5, k) for k in range(tree.n - 1)], [spd(2, k) + np.eye(2) for k in range(tree.n - 1)],
+                      [spd(5, k) for k in range(tree.n_leaf_nodes)])
+        return (tree, cost, dyn, rms, con), {"split_stage": 2}
+    if name == "shared_dense_costs":            # CM_SHARED (not diagonal)
+        tree, cost, dyn, rms, con = S.get_server_heat_specs(5, 5, 2)
+        a = rng.standard_normal((5, 5)); Q = 0.05 * (a @ a.T) / 5 + 0.05 * np.eye(5)
+        return (tree, S.Cost([Q], [np.eye(5) + 0.2 * Q], [Q.copy()]), dyn, rms, con), {"split_stage": 2}
+    if name == "per_node_costs_large_nx":       # CM_GENERAL, run-time dimensions, lane-team sweeps with per-thread local phases
+        tree, cost, dyn, rms, con = S.get_random_linear_specs(4, 10, 3)
+        cost = S.Cost([np.eye(10) * (0.1 + 0.01 * k) for k in range(tree.n - 1)], [np.eye(3) * (1 + 0.05 * k) for k in range(tree.n - 1)],
+                      [np.eye(10) * (0.1 + 0.02 * k) for k in range(tree.n_leaf_nodes)])
+        return (tree, cost, dyn, rms, con), {"split_stage": 2}
+    if name == "soc_risk_cone":                 # second-order sub-cone inside K (general dual-cone projection)
+        tree, cost, dyn, _, con = S.get_server_heat_specs(4, 3, 2)
+        E = np.vstack([0.95 * np.eye(2), -np.eye(2), np.ones((1, 2))]); F = np.zeros((5, 2)); b = np.array([0.3, 0.7, 0, 0, 1.0])
+        rms = S.get_uniform_rms_v2(E, F, b, S.ConvexCone([(S.CONE_SOC, 3), (S.CONE_NONNEG, 1), (S.CONE_REALS, 1)]), 2, 4)
+        return (tree, cost, dyn, rms, con), {}
+    if name == "two_stage_tree":                # N = 2: the root and its leaves only
+        return S.get_server_heat_specs(2, 5, 2, nu=2), {}
+    if name == "d4_tree":                       # branching factor 4 (run-time dimensions)
+        return S.get_server_heat_specs(3, 3, 4, p_ref=[0.1, 0.2, 0.3, 0.4]), {}
+    raise KeyError(name)
+
+
+VARIANTS = ["per_node_dense_costs", "shared_dense_costs", "per_node_costs_large_nx", "soc_risk_cone", "two_stage_tree", "d4_tree"]
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_emulated_variants(S, O, emu, name):
+    specs, kw = _variant_specs(S, name)
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, lib_path=emu, L_norm="auto", **kw)
+    o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm
+    rng = np.random.default_rng(9)
+    for scale in (1.0, 0.05, 5.0):
+        z = rng.standard_normal(flat.nz) * scale; v = rng.standard_normal(flat.nv) * scale; x0 = rng.standard_normal(flat.nx) * 0.1
+        assert relerr(m.L(z), o.L(z)) <= 1e-12 and relerr(m.L_transpose(v), o.Lt(v)) <= 1e-12
+        assert relerr(m.prox_f(z, 0.1, x0), o.prox_f(z, 0.1, x0)) <= 1e-11
+        assert relerr(m.prox_h_conj(v, 0.3), o.prox_h_conj(v, 0.3)) <= 1e-12
+        zo, vo = m.T(z, v, 0.3, 0.25, x0); zr, vr = o.T(z, v, 0.3, 0.25, x0)
+        assert relerr(zo, zr) <= 1e-11 and relerr(vo, vr) <= 1e-11
+    x0 = np.full(flat.nx, 0.1)
+    r = S.solve_model(m, x0, tol=1e-3); ro = o.solve(x0, tol=1e-3)
+    assert (r["iterations"], r["status"]) == (ro["iterations"], ro["status"])
+    assert relerr(m.solver_state.z, o.z) <= 1e-8
+    m.close()
+
+
+def test_emulated_nan_and_state_api(S, O, emu):
+    specs = S.get_server_heat_specs(4, 5, 2, nu=2)
+    flat = S.flatten_problem(*specs)
+    for alg in (S.CP, S.SP):
+        m = S.build_model(*specs, S.SolverOptions(alg, None), lib_path=emu)
+        r = S.solve_model(m, np.array([0.1, np.nan, 0.1, 0.1, 0.1]), tol=1e-3)
+        assert r["status"] == 2 and r["iterations"] <= 2                       # SPOCK_NAN, stops at once
+        m.reset()
+        assert np.all(m.solver_state.z == 0) and np.all(m.solver_state.v == 0)
+        r = S.solve_model(m, np.full(5, 0.1), tol=1e-3)
+        assert r["status"] in (0, 1)
+        z, v = m.solver_state.z.copy(), m.solver_state.v.copy()
+        m.set_state(z * 0.5, v * 0.5)
+        assert np.array_equal(m.solver_state.z, z * 0.5) and np.array_equal(m.solver_state.v, v * 0.5)
+        m.close()
+
+
 def test_unsupported_inputs(S, emu):
     tree, cost, dyn, rms, con = S.get_server_heat_specs(4, 3, 2)
     bad = S.generate_scenario_tree_uniform_branching_factor_v2(4, 2, 3, 3)

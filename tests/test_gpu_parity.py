@@ -108,6 +108,59 @@ def test_cp_solve_matches_oracle(S, O, models, name, tol, verbose):
     assert relerr(m.solver_state.z, o.z) <= 1e-8
 
 
+@pytest.mark.parametrize("name", ["per_node_dense_costs", "shared_dense_costs", "per_node_costs_large_nx", "soc_risk_cone",
+                                  "two_stage_tree", "d4_tree"])
+def test_variants_match_oracle(S, O, name):
+    """Less-travelled kernel paths on the GPU: per-node and dense cost matrices, a second-order part in the risk cone,
+    a two-stage tree, branching factor 4 -- operators and a whole CP solve against the oracle."""
+    from test_emu_driver import _variant_specs
+    specs, kw = _variant_specs(S, name)
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, L_norm="auto", **kw)
+    o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm
+    rng = np.random.default_rng(9)
+    for scale in (1.0, 0.05, 5.0):
+        z = rng.standard_normal(flat.nz) * scale; v = rng.standard_normal(flat.nv) * scale; x0 = rng.standard_normal(flat.nx) * 0.1
+        assert relerr(m.L(z), o.L(z)) <= OP_TOL and relerr(m.L_transpose(v), o.Lt(v)) <= OP_TOL
+        assert relerr(m.prox_f(z, 0.1, x0), o.prox_f(z, 0.1, x0)) <= 1e-11
+        assert relerr(m.prox_h_conj(v, 0.3), o.prox_h_conj(v, 0.3)) <= OP_TOL
+        zo, vo = m.T(z, v, 0.3, 0.25, x0); zr, vr = o.T(z, v, 0.3, 0.25, x0)
+        assert relerr(zo, zr) <= 1e-11 and relerr(vo, vr) <= 1e-11
+    x0 = np.full(flat.nx, 0.1)
+    r = S.solve_model(m, x0, tol=1e-3); ro = o.solve(x0, tol=1e-3)
+    assert (r["iterations"], r["status"]) == (ro["iterations"], ro["status"])
+    assert relerr(m.solver_state.z, o.z) <= 1e-8
+    m.close()
+
+
+def test_large_nx_lane_team_path(S, O):
+    """BASELINE configs 3-5 (nx = 20 / 64): lane-team sweeps and lane-team node-local phases, CP and SP, against the oracle."""
+    for specs, kw in ((S.get_server_heat_specs(6, 20, 2), {}), (S.get_server_heat_specs(5, 20, 3, p_ref=[0.2, 0.3, 0.5]), {}),
+                      (S.get_random_linear_specs(6, 64, 16), {})):
+        flat = S.flatten_problem(*specs)
+        m = S.build_model(*specs, L_norm="auto", **kw)
+        o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm
+        rng = np.random.default_rng(2)
+        z = rng.standard_normal(flat.nz); v = rng.standard_normal(flat.nv); x0 = np.full(flat.nx, 0.1)
+        zo, vo = m.T(z, v, 0.3, 0.25, x0); zr, vr = o.T(z, v, 0.3, 0.25, x0)
+        assert relerr(zo, zr) <= 1e-11 and relerr(vo, vr) <= 1e-11
+        assert relerr(m.L(z), o.L(z)) <= OP_TOL and relerr(m.L_transpose(v), o.Lt(v)) <= OP_TOL
+        r = S.solve_model(m, x0, tol=1e-3, verbose=S.LOG); ro = o.solve(x0, tol=1e-3, verbose=O.LOG, history=6000)
+        assert (r["iterations"], r["status"]) == (ro["iterations"], ro["status"])
+        assert relerr(m.solver_state.z, o.z) <= 1e-8
+        assert np.max(np.abs(m.history()["xi"] - ro["hist_xi"]) / ro["hist_xi"]) <= 1e-8
+        m.close()
+    specs = S.get_server_heat_specs(6, 20, 2)
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None)); o = O.Oracle(flat, O.SP)
+    x0 = np.full(20, 0.1)
+    r = S.solve_model(m, x0, tol=1e-3); ro = o.solve(x0, tol=1e-3, history=3000)
+    h = m.history(); n = min(25, len(h["xi1"]), len(ro["hist_xi1"]))
+    assert np.max(np.abs(h["xi1"][:n] - ro["hist_xi1"][:n]) / ro["hist_xi1"][:n]) <= 1e-8
+    assert np.array_equal(h["backtrack"][:n], ro["hist_backtrack"][:n]) and r["status"] == 0
+    m.close()
+
+
 def test_known_answer_trace_cp(S, kat_cp):
     """examples/server_heat/residuals.jl on the GPU: N=7, d=2, nx=nu=5, TOL=1e-5, LOG -> residuals.tikz:29-3187."""
     specs = S.get_server_heat_specs(7, 5, 2)
