@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["spock_kernels.hip", "spock_abi.cpp", "spock_host.cpp", "spock_rt_hip.cpp"]
-HEADERS = ["spock_device.hpp", "spock_group.hpp", "spock_internal.hpp", "spock_rt.hpp", os.path.join("..", "..", "include", "spock_amd.h")]
+HEADERS = ["spock_device.hpp", "spock_group.hpp", "spock_internal.hpp", "spock_rt.hpp", "spock_sp.hpp", "spock_team_local.hpp", os.path.join("..", "..", "include", "spock_amd.h")]
 OUT = os.path.join(HERE, "libspock_amd.so")
 
 

@@ -6,7 +6,9 @@
 // iteration k (should_terminate!, cp.jl:54-123) and, once an instance is done, every later kernel for
 // it exits immediately, so the state freezes at exactly the iterate the reference would stop at.  The
 // host replays a captured hipGraph of `graph_iters` iterations and polls the control blocks in between.
-// z/v ping-pong between two buffers ("z <- zbar" at lambda = 1 is a pointer swap, cp.jl:34-52).
+// "z <- zbar" at lambda = 1 is a pointer swap (cp.jl:34-52): v ping-pongs between two buffers, z rotates through
+// three (iteration k reads slot k % 3, writes zbar to (k+1) % 3, and the fused kernel's early phase A of iteration
+// k + 1 writes to (k+2) % 3), so the buffer roles repeat with period 6 = `parity` of a launch.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +32,8 @@ struct spock_handle_s {
     double L_norm = 10.;
     void *stream = nullptr, *ev0 = nullptr, *ev1 = nullptr, *graph = nullptr;
     // device memory
-    double *d_mats = nullptr, *d_z[2] = {nullptr, nullptr}, *d_v[2] = {nullptr, nullptr};
+    double *d_mats = nullptr, *d_z[3] = {nullptr, nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}, *d_v2x = nullptr;
+    bool fused = false;   // CP iteration = CROWN + SUB_BA (after one SUB_A) instead of SUB_A + CROWN + SUB_B
     double *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_partials = nullptr, *d_x0 = nullptr, *d_hist = nullptr;
     Ctl *d_ctl = nullptr;
     unsigned long long *d_dbg = nullptr;
@@ -73,8 +76,9 @@ KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
     a.dm = h->bp.dm;
     a.mats = h->d_mats;
     if (!op) {
-        a.z_in = h->d_z[parity]; a.v_in = h->d_v[parity];
-        a.z_out = h->d_z[1 - parity]; a.v_out = h->d_v[1 - parity];
+        a.z_in = h->d_z[parity % 3]; a.v_in = h->d_v[parity % 2];
+        a.z_out = h->d_z[(parity + 1) % 3]; a.v_out = h->d_v[(parity + 1) % 2];
+        a.z_next = h->d_z[(parity + 2) % 3]; a.v2x = h->d_v2x;
         a.dbuf = h->d_dbuf; a.qroot = h->d_qroot; a.cbuf = h->d_cbuf; a.partials = h->d_partials; a.ctl = h->d_ctl; a.x0 = h->d_x0;
         a.hist = h->d_hist; a.hist_cap = h->hist_cap; a.batch = h->batch; a.dbg = h->d_dbg;
     } else {
@@ -97,6 +101,23 @@ int launch_iteration(spock_handle_s *h, bool op, int parity, unsigned flags, boo
     if (e == 0) e = launch_group(MODE_CROWN, a, h->stream);
     if (e == 0 && phase_b) e = launch_group(MODE_SUB_B, a, h->stream);
     return e;
+}
+
+// CP driver: the kernels of iteration k (k taken modulo 6).  Fused sequence: SUB_A of iteration 0 is launched once per
+// solve (cp_prologue); every iteration is then CROWN + SUB_BA, the latter already running phase A and the backward
+// sweep of iteration k + 1.
+int launch_cp_iteration(spock_handle_s *h, int k, unsigned flags = 0) {
+    const KArgs a = make_args(h, false, k % 6, flags);
+    if (h->bp.dm.t0 == 0) return launch_group(MODE_FULL, a, h->stream);
+    int e = 0;
+    if (!h->fused) e = launch_group(MODE_SUB_A, a, h->stream);
+    if (e == 0) e = launch_group(MODE_CROWN, a, h->stream);
+    if (e == 0) e = launch_group(h->fused ? MODE_SUB_BA : MODE_SUB_B, a, h->stream);
+    return e;
+}
+int cp_prologue(spock_handle_s *h, unsigned flags = 0) {
+    if (!h->fused) return 0;
+    return launch_group(MODE_SUB_A, make_args(h, false, 0, flags), h->stream);
 }
 
 int ensure_op_buffers(spock_handle_s *h) {
@@ -328,7 +349,8 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     int gi = o ? o->graph_iters : 0;
     if (const char *e = std::getenv("SPOCK_AMD_GRAPH_ITERS")) gi = std::atoi(e);
     if (gi == 0) gi = (alg == SPOCK_ALG_SP) ? 8 : 32;
-    if (gi > 0 && (gi & 1)) gi += 1;   // an even count brings the ping-pong parity back to 0
+    if (gi > 0 && alg == SPOCK_ALG_CP) gi = ((gi + 5) / 6) * 6;   // a multiple of 6 brings the buffer rotation back to slot 0
+    else if (gi > 0 && (gi & 1)) gi += 1;
     h->graph_iters = gi;
     int split = o ? o->split_stage : 0;
     if (const char *e = std::getenv("SPOCK_AMD_SPLIT_STAGE")) split = std::atoi(e);
@@ -352,9 +374,10 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     if ((e = dev_alloc(h, &h->d_mats, h->bp.mats.size()))) return bail(e, "hipMalloc(matrix pool)");
     if ((e = rt::h2d(h->d_mats, h->bp.mats.data(), h->bp.mats.size() * sizeof(double), h->stream))) return bail(e, "upload");
     if (alg == SPOCK_ALG_CP) {
-        for (int k = 0; k < 2; ++k) {
-            if ((e = dev_alloc(h, &h->d_z[k], B * dm.nz)) || (e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
-        }
+        for (int k = 0; k < 3; ++k) if ((e = dev_alloc(h, &h->d_z[k], B * dm.nz))) return bail(e, "hipMalloc(state)");
+        for (int k = 0; k < 2; ++k) if ((e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
+        if ((e = dev_alloc(h, &h->d_v2x, B * (size_t)dm.nsub))) return bail(e, "hipMalloc(state)");
+        h->fused = dm.t0 > 0 && !launch_geometry(MODE_SUB_B, dm, h->batch).team_local && !std::getenv("SPOCK_AMD_NO_FUSE");
     } else {
         const size_t nr = (size_t)dm.nz + dm.nv;
         for (int k = 0; k < 10; ++k) if ((e = dev_alloc(h, &h->s_vec[k], B * nr))) return bail(e, "hipMalloc(SP state)");
@@ -483,7 +506,7 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
     if (use_graph && !h->graph) {
         RTCHECK(rt::capture_begin(h->stream));
         int e = 0;
-        for (int it = 0; it < G && e == 0; ++it) e = launch_iteration(h, false, it & 1, 0);
+        for (int it = 0; it < G && e == 0; ++it) e = launch_cp_iteration(h, it);
         void *exec = nullptr;
         const int e2 = rt::capture_end(h->stream, &exec);
         if (e) return fail(SPOCK_ERR_HIP, std::string("kernel launch during capture: ") + rt::err(e));
@@ -491,11 +514,12 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
         h->graph = exec;
     }
     RTCHECK(rt::event_record(h->ev0, h->stream));
+    RTCHECK(cp_prologue(h));
     const int max_reps = (h->max_iter + 1 + G - 1) / G + 2;
     bool all_done = false;
     for (int rep = 0; rep < max_reps && !all_done; ++rep) {
         if (use_graph) RTCHECK(rt::graph_launch(h->graph, h->stream));
-        else for (int it = 0; it < G; ++it) RTCHECK(launch_iteration(h, false, it & 1, 0));
+        else for (int it = 0; it < G; ++it) RTCHECK(launch_cp_iteration(h, it));
         RTCHECK(launch_group(MODE_FINALIZE, make_args(h, false, 0, 0), h->stream));
         RTCHECK(rt::d2h(h->h_ctl.data(), h->d_ctl, B * sizeof(Ctl), h->stream));
         RTCHECK(rt::sync(h->stream));
@@ -511,10 +535,8 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
     int evals = 0;
     for (size_t b = 0; b < B; ++b) {
         const Ctl &c = h->h_ctl[b];
-        if (c.result_parity == 1) {
-            RTCHECK(rt::d2d(h->d_z[0] + b * dm.nz, h->d_z[1] + b * dm.nz, sizeof(double) * dm.nz, h->stream));
-            RTCHECK(rt::d2d(h->d_v[0] + b * dm.nv, h->d_v[1] + b * dm.nv, sizeof(double) * dm.nv, h->stream));
-        }
+        if (c.result_parity % 3) RTCHECK(rt::d2d(h->d_z[0] + b * dm.nz, h->d_z[c.result_parity % 3] + b * dm.nz, sizeof(double) * dm.nz, h->stream));
+        if (c.result_parity % 2) RTCHECK(rt::d2d(h->d_v[0] + b * dm.nv, h->d_v[1] + b * dm.nv, sizeof(double) * dm.nv, h->stream));
         if (c.evals > evals) evals = c.evals;
         if (results) {
             spock_result_t &r = results[b];
@@ -573,10 +595,8 @@ int spock_set_state(spock_handle_t h, const double *z, const double *v) {
 int spock_reset(spock_handle_t h) {
     if (!h) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
     if (h->alg == SPOCK_ALG_SP) { RTCHECK(sp_init_state(h)); return SPOCK_OK; }
-    for (int k = 0; k < 2; ++k) {
-        RTCHECK(rt::dzero(h->d_z[k], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
-        RTCHECK(rt::dzero(h->d_v[k], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
-    }
+    for (int k = 0; k < 3; ++k) RTCHECK(rt::dzero(h->d_z[k], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
+    for (int k = 0; k < 2; ++k) RTCHECK(rt::dzero(h->d_v[k], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
 }
@@ -664,7 +684,8 @@ int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_
     if (!h || !avg_ms || reps < 1) return fail(SPOCK_ERR_BAD_ARG, "bad argument");
     if (h->alg != SPOCK_ALG_CP) return fail(SPOCK_ERR_UNSUPPORTED, "kernel profiling is implemented for CP handles");
     // `reps` further CP iterations on the current state, launched one kernel at a time with a HIP event before
-    // and after each launch on the handle's stream; per kind: 0 SUB_A, 1 CROWN, 2 SUB_B, 3 FULL.
+    // and after each launch on the handle's stream; per kind: 0 SUB_A, 1 CROWN, 2 SUB_B or the fused SUB_BA, 3 FULL.
+    // (With the fused sequence SUB_A runs once, ahead of the first iteration.)
     const size_t B = (size_t)h->batch;
     const double g = 0.99 / std::sqrt(h->L_norm);
     Ctl c = fresh_ctl(h, g, g, 0., SPOCK_SILENT);
@@ -672,40 +693,39 @@ int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_
     std::vector<Ctl> cs(B, c);
     RTCHECK(rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream));
     const bool split = h->bp.dm.t0 > 0;
-    const int kinds[3] = {MODE_SUB_A, MODE_CROWN, MODE_SUB_B};
-    const int per_it = split ? 3 : 1;
-    std::vector<void *> ev((size_t)reps * per_it * 2, nullptr);
-    for (auto &e : ev) RTCHECK(rt::event_create(&e));
-    size_t k = 0;
+    unsigned dbg = 0;
+    if (const char *e = std::getenv("SPOCK_AMD_DEBUG_FLAGS")) dbg = (unsigned)std::atoi(e);
+    std::vector<int> seq;   // (mode, iteration) of every launch, in order
+    std::vector<int> seq_it;
+    if (split && h->fused) { seq.push_back(MODE_SUB_A); seq_it.push_back(0); }
     for (int it = 0; it < reps; ++it) {
-        unsigned dbg = 0;
-        if (const char *e = std::getenv("SPOCK_AMD_DEBUG_FLAGS")) dbg = (unsigned)std::atoi(e);
-        const KArgs a = make_args(h, false, it & 1, dbg);
-        for (int j = 0; j < per_it; ++j) {
-            RTCHECK(rt::event_record(ev[k++], h->stream));
-            RTCHECK(launch_group(split ? kinds[j] : MODE_FULL, a, h->stream));
-            RTCHECK(rt::event_record(ev[k++], h->stream));
-        }
+        if (!split) { seq.push_back(MODE_FULL); seq_it.push_back(it); continue; }
+        if (!h->fused) { seq.push_back(MODE_SUB_A); seq_it.push_back(it); }
+        seq.push_back(MODE_CROWN); seq_it.push_back(it);
+        seq.push_back(h->fused ? MODE_SUB_BA : MODE_SUB_B); seq_it.push_back(it);
+    }
+    std::vector<void *> ev(seq.size() * 2, nullptr);
+    for (auto &e : ev) RTCHECK(rt::event_create(&e));
+    for (size_t k = 0; k < seq.size(); ++k) {
+        const KArgs a = make_args(h, false, seq_it[k] % 6, dbg);
+        RTCHECK(rt::event_record(ev[2 * k], h->stream));
+        RTCHECK(launch_group(seq[k], a, h->stream));
+        RTCHECK(rt::event_record(ev[2 * k + 1], h->stream));
     }
     RTCHECK(rt::sync(h->stream));
     double sum[4] = {0., 0., 0., 0.};
     int cnt[4] = {0, 0, 0, 0};
-    k = 0;
-    for (int it = 0; it < reps; ++it)
-        for (int j = 0; j < per_it; ++j) {
-            float ms = 0.f;
-            RTCHECK(rt::event_elapsed(&ms, ev[k], ev[k + 1]));
-            k += 2;
-            const int kind = split ? j : 3;
-            sum[kind] += ms; cnt[kind] += 1;
-        }
+    for (size_t k = 0; k < seq.size(); ++k) {
+        float ms = 0.f;
+        RTCHECK(rt::event_elapsed(&ms, ev[2 * k], ev[2 * k + 1]));
+        const int kind = seq[k] == MODE_SUB_A ? 0 : seq[k] == MODE_CROWN ? 1 : seq[k] == MODE_FULL ? 3 : 2;
+        sum[kind] += ms; cnt[kind] += 1;
+    }
     for (auto e : ev) rt::event_destroy(e);
     for (int q = 0; q < 4; ++q) { avg_ms[q] = cnt[q] ? sum[q] / cnt[q] : 0.; if (launches) launches[q] = cnt[q]; }
-    // leave a consistent state behind: an odd number of iterations ends in buffer 1
-    if (reps & 1) {
-        RTCHECK(rt::d2d(h->d_z[0], h->d_z[1], B * h->bp.dm.nz * sizeof(double), h->stream));
-        RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * h->bp.dm.nv * sizeof(double), h->stream));
-    }
+    // leave a consistent state behind: the iterate after `reps` iterations goes back to slot 0
+    if (reps % 3) RTCHECK(rt::d2d(h->d_z[0], h->d_z[reps % 3], B * h->bp.dm.nz * sizeof(double), h->stream));
+    if (reps % 2) RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * h->bp.dm.nv * sizeof(double), h->stream));
     for (auto &x : cs) x.done = 1;
     RTCHECK(rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream));
     RTCHECK(rt::sync(h->stream));

@@ -178,7 +178,8 @@ SPK_DEV void init_geometry(const P &p, const Dims &dm, int tau, int root_stage, 
 // node-local terms of the S1 recursion: c_i = U_t ubar_i - xbar_i and e_i = Rt^-1 ubar_i (spock_host.cpp).
 template <class P>
 SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
-                     const double *__restrict__ v, double *__restrict__ zo, TState<P> &s, double gamma, unsigned flags) {
+                     const double *__restrict__ v, double *__restrict__ zo, TState<P> &s, double gamma, unsigned flags,
+                     const double *v2x = nullptr) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu;
     const double mg = -gamma;
@@ -212,7 +213,8 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = s.c0 + c;
         double ls;
-        if (j < dm.nn) ls = v[dm.o2 + j];
+        if (v2x && s.kids_gleaf) ls = v2x[s.pos * d + c];   // crown workgroup of the fused B+A kernel, children = subtree roots
+        else if (j < dm.nn) ls = v[dm.o2 + j];
         else ls = 0.5 * v[dm.o12 + (j - dm.nn)] + 0.5 * v[dm.o13 + (j - dm.nn)];
         vec[ny + c] = mg * ls + z[dm.zs + j];
         vec[ny + d + c] = mg * (0.5 * v[dm.o5 + j - 1] + 0.5 * v[dm.o6 + j - 1]) + z[dm.zt + j - 1];
@@ -481,6 +483,27 @@ struct ProxScal {
     double inv_sigma_neg, inv_gamma_neg;         // -1/sigma, -1/gamma as the reference forms them (cp.jl:73-75)
     bool want_xi;                                // LOG-mode CP: xi = xi_1 + L' xi_2 (cp.jl:83-86)
 };
+
+// vbar.v2 of node j alone, the same arithmetic as b_local's risk block.  The fused B+A kernel's crown workgroup needs
+// it for the subtree roots, whose own threads sit in other workgroups of the same launch.
+template <class P>
+SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, const double *z, const double *v, const double *zb, int j,
+                            const ProxScal &ps) {
+    const int ny = p.ny();
+    const MatPtr bb = M + dm.mb;
+    double bw = 0.;
+    SPK_UNROLL for (int k = 0; k < ny; ++k) {
+        const double zbk = zb[dm.zy + j * ny + k], zk = z[dm.zy + j * ny + k];
+        const double wy = 2. * zbk + -1. * zk;
+        bw += bb[k] * wy;
+    }
+    const double zbs = zb[dm.zs + j], zs_ = z[dm.zs + j];
+    const double ws = 2. * zbs + -1. * zs_;
+    double t2 = ps.sigma * (ws - bw) + v[dm.o2 + j];
+    t2 = t2 * ps.inv_sigma;
+    const double p2 = t2 >= 0. ? t2 : 0.;
+    return ps.sigma * (t2 - p2);
+}
 
 template <class P>
 SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,

@@ -22,6 +22,9 @@
 #pragma once
 #include "spock_device.hpp"
 #include "spock_team_local.hpp"
+#ifdef SPOCK_HOST_EMU
+#include <cstdlib>
+#endif
 
 namespace spock {
 
@@ -94,7 +97,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     double *ex = x.lds();
 
     // ---- geometry of this group
-    const bool sub = (MODE == MODE_SUB_A || MODE == MODE_SUB_B);
+    const bool sub = (MODE == MODE_SUB_A || MODE == MODE_SUB_B || MODE == MODE_SUB_BA);
     const bool crown_blk = sub && (g == dm.nsub);          // the extra workgroup of SUB_A / SUB_B
     const bool crown = (MODE == MODE_CROWN) || crown_blk;
     const int root_stage = (sub && !crown_blk) ? dm.t0 : 0;
@@ -140,7 +143,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // across it produced wrong iterates on the GPU in the 512-thread crown -- the control section stays first.)
     //   crown : c_i / e_i of the crown nodes (cbuf) and q of the subtree roots (qroot)
     //   SUB_B : d_i of the subtree's nodes (dbuf)
-    const int st_n1 = (MODE == MODE_CROWN) ? nl_grp * nxu : ((MODE == MODE_SUB_B && !crown_blk) ? nl_grp * p.nu() : 0);
+    const int st_n1 = (MODE == MODE_CROWN) ? nl_grp * nxu : (((MODE == MODE_SUB_B || MODE == MODE_SUB_BA) && !crown_blk) ? nl_grp * p.nu() : 0);
     const int st_n2 = (MODE == MODE_CROWN) ? ngl_grp * p.nx() : 0;
     const bool staged = team && (st_n1 + st_n2 > 0) && (st_n1 + st_n2 <= kStageRegs * x.nthreads());
     if (staged) {
@@ -166,87 +169,84 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     }
 
     const double gamma = ctl.gamma, sigma = ctl.sigma;
-
-    // ---- phase A (node-local)
+    const int nx = p.nx(), nu = p.nu(), d = p.d(), nthr = x.nthreads();
+    auto level_geo = [&](int l, int &lfirst, int &cnt, long &gfirst) {
+        cnt = 1; lfirst = 0;
+        for (int k = 0; k < l; ++k) { lfirst += cnt; cnt *= d; }
+        gfirst = dm.first[root_stage + l] + (long)root_pos * cnt;
+    };
     // lane-team node-local phases (large nx / nu, diagonal costs): T lanes per node, team scratch behind the sweep vectors
     const bool team_local = P::TEAMLOCAL;
-    const int TT = a.team > 0 ? a.team : 8, nteams = x.nthreads() / TT;
-    double *tscr = tl.XL + ngl_grp * p.nx();
-    const int tscr_stride = team_scratch_doubles(p.nu(), p.ny() + 2 * p.d(), p.d(), TT);
-    if (team_local && (MODE == MODE_FULL || MODE == MODE_SUB_A) && !(flags & F_NO_ALOCAL)) {
-        for (int base = 0; base < nl_grp; base += nteams) {
-            x.each([&](int tid, TState<P> &s) {
-                const int tm = tid / TT, r = tid - tm * TT;
-                if (tm >= nteams) return;
-                const TeamNode tn = team_node(dm, p.d(), base + tm, nl_grp, root_stage, root_pos, stages, crown);
-                ta_p1(p, dm, M, z, v, zo, tn, r, TT, tscr + tm * tscr_stride, crown_blk ? nullptr : tl.XL, gamma, flags, s.tlr);
-            });
-            x.barrier();
-            if (!(flags & F_RAW_LT))
+    const int TT = a.team > 0 ? a.team : 8, nteams = nthr / TT;
+    double *tscr = tl.XL + ngl_grp * nx;
+    const int tscr_stride = team_scratch_doubles(nu, p.ny() + 2 * d, d, TT);
+
+    // ---- phase A (node-local) on the iterate (zi, vi); its part of zbar goes to zout, c_i / e_i (and the leaves' xbar) to
+    //      the thread state or the lane teams' LDS vectors, for the crown's extra workgroup to cbuf
+    auto phase_a = [&](const double *zi, const double *vi, double *zout, const double *v2x) {
+        if (flags & F_NO_ALOCAL) return;
+        if (team_local) {
+            for (int base = 0; base < nl_grp; base += nteams) {
                 x.each([&](int tid, TState<P> &s) {
                     const int tm = tid / TT, r = tid - tm * TT;
                     if (tm >= nteams) return;
-                    const TeamNode tn = team_node(dm, p.d(), base + tm, nl_grp, root_stage, root_pos, stages, crown);
-                    double *cq = crown_blk ? cb + tn.li * p.nx() : tl.XQ + tn.li * p.nx();
-                    double *ce = crown_blk ? cb + nl_grp * p.nx() + tn.li * p.nu() : tl.ED + tn.li * p.nu();
-                    ta_p2(p, dm, M, zo, tn, r, TT, tscr + tm * tscr_stride, cq, ce, s.tlr);
+                    const TeamNode tn = team_node(dm, d, base + tm, nl_grp, root_stage, root_pos, stages, crown);
+                    ta_p1(p, dm, M, zi, vi, zout, tn, r, TT, tscr + tm * tscr_stride, crown_blk ? nullptr : tl.XL, gamma, flags, s.tlr);
                 });
-            x.barrier();
+                x.barrier();
+                if (!(flags & F_RAW_LT))
+                    x.each([&](int tid, TState<P> &s) {
+                        const int tm = tid / TT, r = tid - tm * TT;
+                        if (tm >= nteams) return;
+                        const TeamNode tn = team_node(dm, d, base + tm, nl_grp, root_stage, root_pos, stages, crown);
+                        double *cq = crown_blk ? cb + tn.li * nx : tl.XQ + tn.li * nx;
+                        double *ce = crown_blk ? cb + nl_grp * nx + tn.li * nu : tl.ED + tn.li * nu;
+                        ta_p2(p, dm, M, zout, tn, r, TT, tscr + tm * tscr_stride, cq, ce, s.tlr);
+                    });
+                x.barrier();
+            }
+            return;
         }
-        if (crown_blk) return;
-    }
-    if (!team_local && (MODE == MODE_FULL || MODE == MODE_SUB_A) && !(flags & F_NO_ALOCAL)) {
-        x.each([&](int, TState<P> &s) { if (s.active) a_local(p, dm, M, z, v, zo, s, gamma, flags); });
+        x.each([&](int, TState<P> &s) { if (s.active) a_local(p, dm, M, zi, vi, zout, s, gamma, flags, v2x); });
         if (team && !crown_blk) {   // hand c_i, e_i and the leaves' q = -xbar over to the lane teams
             x.each([&](int tid, TState<P> &s) {
                 if (!s.active) return;
-                for (int k = 0; k < p.nx(); ++k) tl.XQ[tid * p.nx() + k] = s.xb[k];
-                for (int k = 0; k < p.nu(); ++k) tl.ED[tid * p.nu() + k] = s.ub[k];
+                for (int k = 0; k < nx; ++k) tl.XQ[tid * nx + k] = s.xb[k];
+                for (int k = 0; k < nu; ++k) tl.ED[tid * nu + k] = s.ub[k];
                 if (s.kids_leaf)
-                    for (int c = 0; c < p.d(); ++c)
-                        for (int k = 0; k < p.nx(); ++k) tl.XL[(s.pos * p.d() + c) * p.nx() + k] = -s.xl[c][k];
+                    for (int c = 0; c < d; ++c)
+                        for (int k = 0; k < nx; ++k) tl.XL[(s.pos * d + c) * nx + k] = -s.xl[c][k];
             });
         }
-        if (crown_blk) {
-            if (!(flags & F_NO_SWEEP))
-                x.each([&](int tid, TState<P> &s) {   // layout [c of every crown node | e of every crown node]
-                    if (!s.active) return;
-                    for (int k = 0; k < p.nx(); ++k) cb[tid * p.nx() + k] = s.xb[k];
-                    for (int k = 0; k < p.nu(); ++k) cb[nl_grp * p.nx() + tid * p.nu() + k] = s.ub[k];
-                });
-            return;
-        }
-    }
-    if (MODE == MODE_FULL) x.barrier();   // zbar.s written by the parents is read by the children in phase B
-    stamp();   // 2: phase A done
+        if (crown_blk && !(flags & F_NO_SWEEP))
+            x.each([&](int tid, TState<P> &s) {   // layout [c of every crown node | e of every crown node]
+                if (!s.active) return;
+                for (int k = 0; k < nx; ++k) cb[tid * nx + k] = s.xb[k];
+                for (int k = 0; k < nu; ++k) cb[nl_grp * nx + tid * nu + k] = s.ub[k];
+            });
+    };
 
-    // ---- S1 sweeps, lane-team version (all sweep vectors in LDS)
-    if (sweeping && team) {
-        const int nx = p.nx(), nu = p.nu(), d = p.d(), nthr = x.nthreads();
-        const double *lmB = lm + n_sw;
-        const MatPtr gB = M + dm.mB;
-        auto level_geo = [&](int l, int &lfirst, int &cnt, long &gfirst) {
-            cnt = 1; lfirst = 0;
-            for (int k = 0; k < l; ++k) { lfirst += cnt; cnt *= d; }
-            gfirst = dm.first[root_stage + l] + (long)root_pos * cnt;
-        };
-        if (MODE == MODE_CROWN) {   // c_i, e_i of the crown and q of the subtree roots -> LDS
-            const double *qg = a.qroot + (long)inst * dm.nsub * dm.nx;
-            x.each([&](int tid, TState<P> &s) {
-                if (staged) {   // XQ and ED are adjacent in LDS, exactly like c | e in cbuf
-                    for (int j = 0; j < kStageRegs; ++j) {
-                        const int k = tid + j * nthr;
-                        if (k < st_n1) tl.XQ[k] = s.stg[j];
-                        else if (k < st_n1 + st_n2) tl.XL[k - st_n1] = s.stg[j];
+    // ---- S1 backward sweep over the group's levels; the subtree kernels leave q_root and every d_i in global memory
+    const bool stores_q = (MODE == MODE_SUB_A || MODE == MODE_SUB_BA);
+    auto backward = [&]() {
+        if (!sweeping || (flags & F_DBG_NO_BWD)) return;
+        if (team) {   // lane-team version (all sweep vectors in LDS)
+            if (MODE == MODE_CROWN) {   // c_i, e_i of the crown and q of the subtree roots -> LDS
+                const double *qg = a.qroot + (long)inst * dm.nsub * dm.nx;
+                x.each([&](int tid, TState<P> &s) {
+                    if (staged) {   // XQ and ED are adjacent in LDS, exactly like c | e in cbuf
+                        for (int j = 0; j < kStageRegs; ++j) {
+                            const int k = tid + j * nthr;
+                            if (k < st_n1) tl.XQ[k] = s.stg[j];
+                            else if (k < st_n1 + st_n2) tl.XL[k - st_n1] = s.stg[j];
+                        }
+                    } else {
+                        for (int k = tid; k < nl_grp * nx; k += nthr) tl.XQ[k] = cb[k];
+                        for (int k = tid; k < nl_grp * nu; k += nthr) tl.ED[k] = cb[nl_grp * nx + k];
+                        for (int k = tid; k < ngl_grp * nx; k += nthr) tl.XL[k] = qg[k];
                     }
-                } else {
-                    for (int k = tid; k < nl_grp * nx; k += nthr) tl.XQ[k] = cb[k];
-                    for (int k = tid; k < nl_grp * nu; k += nthr) tl.ED[k] = cb[nl_grp * nx + k];
-                    for (int k = tid; k < ngl_grp * nx; k += nthr) tl.XL[k] = qg[k];
-                }
-            });
-        }
-        if (MODE != MODE_SUB_B && !(flags & F_DBG_NO_BWD)) {
+                });
+            }
             x.barrier();
             stamp();   // team vectors in LDS
             for (int l = stages - 2; l >= 0; --l) {
@@ -264,7 +264,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 x.barrier();
                 stamp();   // one per backward level
             }
-            if (MODE == MODE_SUB_A) {   // q at the subtree root and every d_i -> HBM (level chunks are contiguous)
+            if (stores_q) {   // q at the subtree root and every d_i -> HBM (level chunks are contiguous)
                 double *q_out = a.qroot + ((long)inst * dm.nsub + g) * dm.nx;
                 double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
                 x.each([&](int tid, TState<P> &) {
@@ -276,15 +276,51 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     }
                 });
             }
+            return;
         }
-        if (MODE != MODE_SUB_A && !(flags & F_DBG_NO_FWD)) {
-            const double *xroot = (MODE == MODE_SUB_B) ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
-            const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+        // one-thread-per-node version (fallback when the team vectors do not fit in LDS, and the batched regime)
+        if (MODE == MODE_CROWN) {
+            x.each([&](int tid, TState<P> &s) {
+                if (!s.active) return;
+                for (int k = 0; k < nx; ++k) s.xb[k] = cb[tid * nx + k];
+                for (int k = 0; k < nu; ++k) s.ub[k] = cb[nl_grp * nx + tid * nu + k];
+            });
+        }
+        const double *qg = (MODE == MODE_CROWN) ? a.qroot + (long)inst * dm.nsub * dm.nx : nullptr;
+        double *q_out = stores_q ? a.qroot + ((long)inst * dm.nsub + g) * dm.nx : nullptr;
+        for (int l = stages - 2; l >= 0; --l) {
+            if (lds_mats) {
+                const double *SW = lm + l * dm.sw_stride;
+                x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) bwd_node(p, dm, SW, tid, ex, qg, q_out, s); });
+            } else {
+                const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
+                x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) bwd_node(p, dm, SW, tid, ex, qg, q_out, s); });
+            }
+            x.barrier();
+            stamp();   // one per backward level
+        }
+        if (stores_q) {
+            double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+            x.each([&](int, TState<P> &s) {
+                if (s.active) for (int k = 0; k < nu; ++k) db[s.node * nu + k] = s.dd[k];
+            });
+        }
+    };
+
+    // ---- S1 forward roll-out from the group root; x_i, u_i (and the group leaves' x) go to zbar and the thread state
+    const bool loads_d = (MODE == MODE_SUB_B || MODE == MODE_SUB_BA);
+    auto forward = [&]() {
+        if (!sweeping || (flags & F_DBG_NO_FWD)) return;
+        const double *xroot = loads_d ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
+        const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+        if (team) {
+            const double *lmB = lm + n_sw;
+            const MatPtr gB = M + dm.mB;
             x.each([&](int tid, TState<P> &s) {
                 if (tid < nx) tl.XQ[tid] = xroot[tid];
-                if (MODE == MODE_SUB_B && staged) {
+                if (loads_d && staged) {
                     for (int j = 0; j < kStageRegs; ++j) { const int k = tid + j * nthr; if (k < st_n1) tl.ED[k] = s.stg[j]; }
-                } else if (MODE == MODE_SUB_B) {
+                } else if (loads_d) {
                     for (int l = 0; l <= stages - 2; ++l) {
                         int lfirst, cnt; long gfirst;
                         level_geo(l, lfirst, cnt, gfirst);
@@ -327,71 +363,37 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                             for (int k = 0; k < nx; ++k) s.xl[c][k] = tl.XL[(s.pos * d + c) * nx + k];
                 }
             });
+            return;
         }
-    }
-
-    // ---- S1 sweeps, one-thread-per-node version (fallback when the team vectors do not fit in LDS)
-    if (sweeping && !team) {
-        if (MODE == MODE_CROWN) {
-            x.each([&](int tid, TState<P> &s) {
-                if (!s.active) return;
-                for (int k = 0; k < p.nx(); ++k) s.xb[k] = cb[tid * p.nx() + k];
-                for (int k = 0; k < p.nu(); ++k) s.ub[k] = cb[nl_grp * p.nx() + tid * p.nu() + k];
+        if (loads_d) {
+            x.each([&](int, TState<P> &s) {
+                if (s.active) for (int k = 0; k < nu; ++k) s.dd[k] = db[s.node * nu + k];
             });
         }
-        if (MODE != MODE_SUB_B && !(flags & F_DBG_NO_BWD)) {
-            const double *qg = (MODE == MODE_CROWN) ? a.qroot + (long)inst * dm.nsub * dm.nx : nullptr;
-            double *q_out = (MODE == MODE_SUB_A) ? a.qroot + ((long)inst * dm.nsub + g) * dm.nx : nullptr;
-            for (int l = stages - 2; l >= 0; --l) {
-                if (lds_mats) {
-                    const double *SW = lm + l * dm.sw_stride;
-                    x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) bwd_node(p, dm, SW, tid, ex, qg, q_out, s); });
-                } else {
-                    const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
-                    x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) bwd_node(p, dm, SW, tid, ex, qg, q_out, s); });
-                }
-                x.barrier();
-                stamp();   // one per backward level
+        for (int l = 0; l <= stages - 2; ++l) {
+            if (lds_mats) {
+                const double *SW = lm + l * dm.sw_stride, *Bm = lm + n_sw;
+                x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, SW, Bm, tid, ex, xroot, s); });
+            } else {
+                const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride, Bm = M + dm.mB;
+                x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, SW, Bm, tid, ex, xroot, s); });
             }
-            if (MODE == MODE_SUB_A) {
-                double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
-                x.each([&](int, TState<P> &s) {
-                    if (s.active) for (int k = 0; k < p.nu(); ++k) db[s.node * p.nu() + k] = s.dd[k];
-                });
-            }
+            x.barrier();
+            stamp();   // one per forward level
         }
-        if (MODE != MODE_SUB_A && !(flags & F_DBG_NO_FWD)) {
-            if (MODE == MODE_SUB_B) {
-                const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
-                x.each([&](int, TState<P> &s) {
-                    if (s.active) for (int k = 0; k < p.nu(); ++k) s.dd[k] = db[s.node * p.nu() + k];
-                });
-            }
-            const double *xroot = (MODE == MODE_SUB_B) ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
-            for (int l = 0; l <= stages - 2; ++l) {
-                if (lds_mats) {
-                    const double *SW = lm + l * dm.sw_stride, *Bm = lm + n_sw;
-                    x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, SW, Bm, tid, ex, xroot, s); });
-                } else {
-                    const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride, Bm = M + dm.mB;
-                    x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, SW, Bm, tid, ex, xroot, s); });
-                }
-                x.barrier();
-                stamp();   // one per forward level
-            }
-            x.each([&](int, TState<P> &s) { if (s.active) fwd_store(p, dm, zo, s); });
-            stamp();
-        }
-    }
+        x.each([&](int, TState<P> &s) { if (s.active) fwd_store(p, dm, zo, s); });
+        stamp();
+    };
 
     // ---- phase B (node-local) + residual maxima
-    if ((MODE == MODE_FULL || MODE == MODE_SUB_B) && !(flags & F_NO_BLOCAL)) {
-        ProxScal ps;
-        ps.sigma = sigma;
-        ps.inv_sigma = 1. / sigma;
-        ps.inv_sigma_neg = -1. / sigma;
-        ps.inv_gamma_neg = -1. / gamma;
-        ps.want_xi = (ctl.log_mode == 2 && ctl.alg == 1);
+    ProxScal ps;
+    ps.sigma = sigma;
+    ps.inv_sigma = 1. / sigma;
+    ps.inv_sigma_neg = -1. / sigma;
+    ps.inv_gamma_neg = -1. / gamma;
+    ps.want_xi = (ctl.log_mode == 2 && ctl.alg == 1);
+    auto phase_b = [&]() {
+        if (flags & F_NO_BLOCAL) return;
         const unsigned bflags = crown_blk ? (flags | F_NO_SWEEP) : flags;   // the crown's x, u come from zbar
         if (team_local) {
             const bool from_zb = (bflags & F_NO_SWEEP) != 0;
@@ -400,17 +402,17 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 x.each([&](int tid, TState<P> &s) {
                     const int tm = tid / TT, r = tid - tm * TT;
                     if (tm >= nteams) return;
-                    const TeamNode tn = team_node(dm, p.d(), base + tm, nl_grp, root_stage, root_pos, stages, crown);
-                    const double *xs = from_zb ? zo + dm.zx + (long)tn.node * p.nx() : tl.XQ + tn.li * p.nx();
-                    const double *us = from_zb ? zo + dm.zu + (long)tn.node * p.nu() : tl.UL + tn.li * p.nu();
-                    const double *xl = from_zb ? zo + dm.zx + (long)tn.c0 * p.nx() : tl.XL + (tn.pos * p.d()) * p.nx();
-                    tb_p1(p, dm, M, z, v, zo, tn, r, TT, tscr + tm * tscr_stride, xs, us, xl, p.nx(), ps, bflags, s.tlr);
+                    const TeamNode tn = team_node(dm, d, base + tm, nl_grp, root_stage, root_pos, stages, crown);
+                    const double *xs = from_zb ? zo + dm.zx + (long)tn.node * nx : tl.XQ + tn.li * nx;
+                    const double *us = from_zb ? zo + dm.zu + (long)tn.node * nu : tl.UL + tn.li * nu;
+                    const double *xl = from_zb ? zo + dm.zx + (long)tn.c0 * nx : tl.XL + (tn.pos * d) * nx;
+                    tb_p1(p, dm, M, z, v, zo, tn, r, TT, tscr + tm * tscr_stride, xs, us, xl, nx, ps, bflags, s.tlr);
                 });
                 x.barrier();
                 x.each([&](int tid, TState<P> &s) {
                     const int tm = tid / TT, r = tid - tm * TT;
                     if (tm >= nteams) return;
-                    const TeamNode tn = team_node(dm, p.d(), base + tm, nl_grp, root_stage, root_pos, stages, crown);
+                    const TeamNode tn = team_node(dm, d, base + tm, nl_grp, root_stage, root_pos, stages, crown);
                     tb_p2(p, dm, M, z, v, zo, vo, tn, r, TT, tscr + tm * tscr_stride, ps, bflags, s.tlr, s.mx3);
                 });
                 x.barrier();
@@ -423,10 +425,43 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 x.stash3(tid, mx);
             });
         }
-        const int slot = (MODE == MODE_SUB_B) ? g : 0;
+        const int slot = (MODE == MODE_FULL) ? 0 : g;
         x.reduce3();
         x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + tid] = x.red3(tid); });
         stamp();   // phase B done
+    };
+
+    // ---- the kernel's sequence
+    if (MODE == MODE_FULL || MODE == MODE_SUB_A) {
+        phase_a(z, v, zo, nullptr);
+        if (crown_blk) return;
+        if (MODE == MODE_FULL) x.barrier();   // zbar.s written by the parents is read by the children in phase B
+        stamp();   // phase A done
+    }
+    if (MODE == MODE_FULL || MODE == MODE_SUB_A || MODE == MODE_CROWN) backward();
+    if (MODE != MODE_SUB_A) forward();
+    if (MODE == MODE_FULL || MODE == MODE_SUB_B || MODE == MODE_SUB_BA) phase_b();
+    if (MODE == MODE_SUB_BA) {
+        // Fused with the first half of the NEXT iteration, whose input is this iteration's output (z <- zbar at lambda = 1,
+        // cp.jl:34-52): phase A on (zbar, vbar) and the backward sweep.  Its part of the next zbar goes to a third z buffer --
+        // this launch's other workgroups may still be reading z.  Everything phase A reads was written by this thread, by
+        // this workgroup (hence the barrier) or by an earlier launch, with one exception: the crown's workgroup needs
+        // vbar.v2 of the subtree roots, which their own workgroups produce in this same launch; it recomputes them.
+        x.barrier();
+        double *zn = a.z_next + (long)inst * a.stride_z;
+        double *v2x = crown_blk ? a.v2x + (long)inst * dm.nsub : nullptr;
+        if (crown_blk)
+            x.each([&](int, TState<P> &s) {
+                if (s.active && s.kids_gleaf)
+                    for (int c = 0; c < d; ++c) v2x[s.pos * d + c] = risk_v2_only(p, dm, M, z, v, zo, s.c0 + c, ps);
+            });
+#ifdef SPOCK_HOST_EMU
+        if (std::getenv("SPOCK_EMU_NO_V2FIX")) v2x = nullptr;   // negative test: the emulation must expose the hazard the fix removes
+#endif
+        phase_a(zo, vo, zn, v2x);
+        if (crown_blk) return;
+        stamp();
+        backward();
     }
     dump_stamps();
 }

@@ -153,7 +153,7 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     int stage_sets[2], n_sets = 0;
     switch (mode) {
         case MODE_FULL: stage_sets[n_sets++] = dm.N; g.grid_x = 1; break;
-        case MODE_SUB_A: case MODE_SUB_B: stage_sets[n_sets++] = dm.sub_stages; stage_sets[n_sets++] = dm.t0 + 1; g.grid_x = dm.nsub + 1; break;
+        case MODE_SUB_A: case MODE_SUB_B: case MODE_SUB_BA: stage_sets[n_sets++] = dm.sub_stages; stage_sets[n_sets++] = dm.t0 + 1; g.grid_x = dm.nsub + 1; break;
         case MODE_CROWN: stage_sets[n_sets++] = dm.t0 + 1; g.grid_x = 1; break;
         default: stage_sets[n_sets++] = 2; g.grid_x = 1; break;
     }

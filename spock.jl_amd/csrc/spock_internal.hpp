@@ -49,7 +49,7 @@ struct Ctl {
     int evals;          // termination tests run so far (= T evaluations checked)
     int iter;           // the reference's `iter` (cp.jl:203,227)
     int pending;        // an iteration has been issued whose termination test has not run yet
-    int result_parity;  // which of the two (z, v) buffers holds the final iterate
+    int result_parity;  // which buffers hold the final iterate: z buffer result_parity % 3, v buffer result_parity % 2
     int max_iter;
     int log_mode;       // SPOCK_LOG -> absolute xi rule (cp.jl:83-99), else res_0 rule (cp.jl:102-112)
     int alg;
@@ -81,6 +81,8 @@ struct KArgs {
     const double *mats;
     const double *z_in, *v_in;  // input iterate; instance b starts at z_in + b*stride_z, v_in + b*stride_v
     double *z_out, *v_out;      // zbar, vbar (same strides)
+    double *z_next;             // SUB_BA only: where phase A of the NEXT iteration puts its part of the next zbar (third z buffer)
+    double *v2x;                // SUB_BA only: [batch][nsub] vbar.v2 of the subtree roots as recomputed by the crown's workgroup
     long stride_z, stride_v;    // CP: nz, nv (separate arrays); SP: nz + nv for both (z|v concatenated per instance)
     double *dbuf;               // [batch][nn*nu]      S1's d_i between phase A and phase B
     double *qroot;              // [batch][nsub*nx]    S1's q at the subtree roots
@@ -135,7 +137,7 @@ struct SpArgs {
 enum SpOp { SP_FLAT1 = 1, SP_FLAT2, SP_FLAT3, SP_FLAT4, SP_FLAT5, SP_LOP_R, SP_LOP_RT, SP_LOP_DP,
             SP_CTL_A, SP_CTL_B, SP_CTL_C, SP_CTL_D };
 
-enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, MODE_FINALIZE = 4 };
+enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, MODE_FINALIZE = 4, MODE_SUB_BA = 5 };
 
 // ---- host build step (spock_host.cpp) -------------------------------------------------------------
 struct HostProblem {

@@ -51,8 +51,14 @@ struct GpuExec {
     __device__ __forceinline__ double red3(int k) const { return __longlong_as_double((long long)red[k]); }
 };
 
+#ifdef SPOCK_WAVES_PER_EU   // experiment builds only
+#define SPK_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(SPOCK_WAVES_PER_EU)))
+#else
+#define SPK_KERNEL_ATTR
+#endif
+
 template <class P, int MODE>
-__global__ void __launch_bounds__(512) spock_group_kernel(const KArgs a) {
+__global__ void __launch_bounds__(512) SPK_KERNEL_ATTR spock_group_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpuExec<P> x;
     x.ex = smem;
@@ -83,12 +89,13 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     const size_t lds = g.lds_bytes;   // sized for the staged matrices either way
     const dim3 grid(g.grid_x, a.batch), block(g.threads);
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: raise it once per kernel (160 KiB per CU on MI355X)
-        static bool raised[5] = {false, false, false, false, false};
+        static bool raised[6] = {false, false, false, false, false, false};
         if (!raised[mode]) {
             const void *fn = mode == MODE_FULL ? (const void *)spock_group_kernel<P, MODE_FULL>
                            : mode == MODE_SUB_A ? (const void *)spock_group_kernel<P, MODE_SUB_A>
                            : mode == MODE_CROWN ? (const void *)spock_group_kernel<P, MODE_CROWN>
                            : mode == MODE_SUB_B ? (const void *)spock_group_kernel<P, MODE_SUB_B>
+                           : mode == MODE_SUB_BA ? (const void *)spock_group_kernel<P, P::TEAMLOCAL ? MODE_SUB_B : MODE_SUB_BA>
                                                 : (const void *)spock_group_kernel<P, MODE_FINALIZE>;
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
@@ -101,13 +108,20 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
         case MODE_CROWN: hipLaunchKernelGGL((spock_group_kernel<P, MODE_CROWN>), grid, block, lds, st, a); break;
         case MODE_SUB_B: hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_B>), grid, block, lds, st, a); break;
         case MODE_FINALIZE: hipLaunchKernelGGL((spock_group_kernel<P, MODE_FINALIZE>), grid, block, lds, st, a); break;
+        case MODE_SUB_BA:
+            // the fused kernel exists for the per-thread node-local phases only
+            if constexpr (P::TEAMLOCAL) return (int)hipErrorInvalidConfiguration;
+            else hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_BA>), grid, block, lds, st, a);
+            break;
         default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();
 }
 
 // compile-time shapes: (nx, nu, d, ny)
+#ifndef SPOCK_STATIC_SHAPES   // (experiment builds narrow the list: tools/build_variant.py)
 #define SPOCK_STATIC_SHAPES(X) X(5, 2, 2, 5) X(5, 5, 2, 5) X(2, 1, 2, 5) X(3, 2, 3, 7)
+#endif
 
 bool have_static_variant(int nx, int nu, int d, int ny) {
 #define X(a, b, c, e) if (nx == a && nu == b && d == c && ny == e) return true;

@@ -57,8 +57,12 @@ static inline int round64(int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; }
 
 template <class P, int MODE>
 static void run_blocks(const KArgs &a, int gx, int thr) {
+    // SPOCK_EMU_REVERSE_BLOCKS=1 runs the workgroups of a launch in the opposite order (the crown's extra workgroup first):
+    // a result must not depend on the order in which the workgroups of one launch run
+    const bool rev = env_on("SPOCK_EMU_REVERSE_BLOCKS");
     for (int inst = 0; inst < a.batch; ++inst)
-        for (int g = 0; g < gx; ++g) {
+        for (int gi = 0; gi < gx; ++gi) {
+            const int g = rev ? gx - 1 - gi : gi;
             EmuExec<P> x(thr, a.ex_doubles, (size_t)a.dm.N * a.dm.sw_stride + (size_t)a.dm.d * a.dm.nx * a.dm.nu);
             group_body<P, MODE>(x, a, inst, g);
         }
@@ -78,6 +82,7 @@ static int launch_variant(int mode, const KArgs &a_in) {
         case MODE_CROWN: run_blocks<P, MODE_CROWN>(a, gx, thr); break;
         case MODE_SUB_B: run_blocks<P, MODE_SUB_B>(a, gx, thr); break;
         case MODE_FINALIZE: run_blocks<P, MODE_FINALIZE>(a, gx, thr); break;
+        case MODE_SUB_BA: if constexpr (P::TEAMLOCAL) return 9; else run_blocks<P, MODE_SUB_BA>(a, gx, thr); break;
         default: return 1;
     }
     return 0;

@@ -327,6 +327,29 @@ def test_emulated_variants(S, O, emu, name):
     m.close()
 
 
+@pytest.mark.parametrize("env,ok", [({}, True), ({"SPOCK_EMU_REVERSE_BLOCKS": "1"}, True), ({"SPOCK_EMU_REVERSE": "1"}, True),
+                                    ({"SPOCK_AMD_NO_FUSE": "1"}, True),
+                                    ({"SPOCK_EMU_REVERSE_BLOCKS": "1", "SPOCK_EMU_NO_V2FIX": "1"}, False)])
+def test_emulated_fused_iteration_is_order_independent(S, O, emu, env, ok, monkeypatch):
+    """CP iteration = CROWN + SUB_BA (phase B of iteration k fused with phase A of k + 1).  The result must not depend on
+    the order in which the workgroups / threads of a launch run, and must equal the unfused three-kernel sequence.  The
+    last case switches off the recomputation of the subtree roots' v2 by the crown's workgroup: the emulation with the
+    crown's workgroup running first must then expose the cross-workgroup read-after-write the recomputation removes."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    specs = S.get_server_heat_specs(7, 5, 2, nu=2)
+    flat = S.flatten_problem(*specs)
+    o = O.Oracle(flat, O.CP)
+    x0 = np.full(flat.nx, 0.1)
+    ro = o.solve(x0, tol=1e-3)
+    for split in (1, 3, 5):
+        m = S.build_model(*specs, lib_path=emu, graph_iters=-6, split_stage=split, batch=2)
+        r = S.solve_model(m, np.stack([x0, 1.3 * x0]), tol=1e-3)
+        good = r[0]["iterations"] == ro["iterations"] and relerr(m.solver_state.z[0], o.z) <= 1e-9 and relerr(m.solver_state.v[0], o.v) <= 1e-9
+        m.close()
+        assert good == ok, (split, env)
+
+
 def test_emulated_nan_and_state_api(S, O, emu):
     specs = S.get_server_heat_specs(4, 5, 2, nu=2)
     flat = S.flatten_problem(*specs)
