@@ -146,6 +146,44 @@ Ctl fresh_ctl(const spock_handle_s *h, double gamma, double sigma, double tol, i
     return c;
 }
 
+// Fused or three-kernel sequence?  The fused kernel saves a launch and the re-read of zbar / vbar, but it is the most
+// register-hungry kernel of the library: for some shapes (nx = nu = 5) the compiler spills in it and the plain sequence
+// is faster.  Decided once per handle by timing a few iterations of both on the zero state, with the handle's own
+// batch size (SPOCK_AMD_FUSE=1 / 0 forces the choice).  The iterates of the two sequences agree to rounding.
+int choose_cp_sequence(spock_handle_s *h) {
+    if (const char *e = std::getenv("SPOCK_AMD_FUSE")) { h->fused = (e[0] == '1'); return 0; }
+    if (std::getenv("SPOCK_AMD_NO_FUSE")) { h->fused = false; return 0; }
+    if (!rt::timing_supported()) return 0;
+    const size_t B = (size_t)h->batch;
+    const Dims &dm = h->bp.dm;
+    Ctl c = fresh_ctl(h, 0.3, 0.3, 0., SPOCK_SILENT);
+    c.max_iter = 1 << 30;
+    std::vector<Ctl> cs(B, c);
+    double best[2] = {1e30, 1e30};
+    int e = 0;
+    for (int trial = 0; trial < 3 && !e; ++trial)
+        for (int f = 0; f < 2 && !e; ++f) {
+            h->fused = (f == 1);
+            if ((e = rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream))) break;
+            if ((e = rt::event_record(h->ev0, h->stream))) break;
+            e = cp_prologue(h);
+            for (int it = 0; it < 6 && !e; ++it) e = launch_cp_iteration(h, it);
+            if (!e) e = rt::event_record(h->ev1, h->stream);
+            if (!e) e = rt::sync(h->stream);
+            float ms = 0.f;
+            if (!e) e = rt::event_elapsed(&ms, h->ev0, h->ev1);
+            if (!e && trial > 0 && ms < best[f]) best[f] = ms;   // trial 0 warms up (code upload, caches)
+        }
+    if (e) return e;
+    h->fused = best[1] <= best[0];
+    for (int k = 0; k < 3 && !e; ++k) e = rt::dzero(h->d_z[k], B * dm.nz * sizeof(double), h->stream);
+    for (int k = 0; k < 2 && !e; ++k) e = rt::dzero(h->d_v[k], B * dm.nv * sizeof(double), h->stream);
+    for (auto &x : cs) x.done = 1;
+    if (!e) e = rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream);
+    if (!e) e = rt::sync(h->stream);
+    return e;
+}
+
 // run one operator-style launch sequence: inputs (may be null = zeros) -> op buffers -> outputs
 int run_op(spock_handle_s *h, const double *z_in, const double *v_in, const double *zbar_in, const double *x0,
            double gamma, double sigma, unsigned flags, bool phase_a, bool phase_b, double *z_out, double *v_out) {
@@ -377,7 +415,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         for (int k = 0; k < 3; ++k) if ((e = dev_alloc(h, &h->d_z[k], B * dm.nz))) return bail(e, "hipMalloc(state)");
         for (int k = 0; k < 2; ++k) if ((e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
         if ((e = dev_alloc(h, &h->d_v2x, B * (size_t)dm.nsub))) return bail(e, "hipMalloc(state)");
-        h->fused = dm.t0 > 0 && !launch_geometry(MODE_SUB_B, dm, h->batch).team_local && !std::getenv("SPOCK_AMD_NO_FUSE");
+        h->fused = dm.t0 > 0 && !launch_geometry(MODE_SUB_B, dm, h->batch).team_local;
     } else {
         const size_t nr = (size_t)dm.nz + dm.nv;
         for (int k = 0; k < 10; ++k) if ((e = dev_alloc(h, &h->s_vec[k], B * nr))) return bail(e, "hipMalloc(SP state)");
@@ -396,6 +434,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     h->h_ctl.assign(B, fresh_ctl(h, 0., 0., 0., SPOCK_SILENT));
     for (auto &c : h->h_ctl) c.done = 1;
     if ((e = rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream))) return bail(e, "upload");
+    if (alg == SPOCK_ALG_CP && h->fused && (e = choose_cp_sequence(h))) return bail(e, "timing the CP kernel sequences");
     if (alg == SPOCK_ALG_SP && (e = sp_init_state(h))) return bail(e, "SP state initialisation");
     if ((e = rt::sync(h->stream))) return bail(e, "hipStreamSynchronize");
     *out = h;

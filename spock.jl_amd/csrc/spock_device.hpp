@@ -414,8 +414,11 @@ SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
 // it loads its rows of W, V, ABK, B, K of its node's stage once, up front, so that a tree level costs one LDS read of
 // the children's / parent's vector, ~2 d nx FMAs, one LDS write and the barrier -- no memory access on the dependent
 // path.  Needs T * (group non-leaf nodes) <= workgroup size; vectors in LDS as for the other team sweep (TeamLds).
+// which: 1 = rows of the backward sweep (W, V), 2 = rows of the forward sweep (ABK, B, K), 3 = both.  A kernel that runs the
+// forward sweep first and the backward sweep last (SUB_BA) loads them in two steps so that the second set is not live
+// across the node-local phases (with both sets live the fused kernel spills registers).
 template <class P>
-SPK_DEV void team_reg_init(const P &p, const Dims &dm, MatPtr M, int root_stage, int stages, int T, int tid, TState<P> &s) {
+SPK_DEV void team_reg_init(const P &p, const Dims &dm, MatPtr M, int root_stage, int stages, int T, int tid, TState<P> &s, int which = 3) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
     const int li = tid / T, r = tid - li * T;
     int lvl = 0, first = 0, cnt = 1;
@@ -427,15 +430,21 @@ SPK_DEV void team_reg_init(const P &p, const Dims &dm, MatPtr M, int root_stage,
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const MatPtr W = SW + dm.sw_oW + c * nx * nx, V = SW + dm.sw_oV + c * nu * nx, A = SW + dm.sw_oABK + c * nx * nx;
         const MatPtr B = M + dm.mB + slot_event(c, d) * nx * nu;
-        SPK_UNROLL for (int k = 0; k < nx; ++k) {
-            s.tW[c][k] = (r < nx) ? W[r + k * nx] : 0.;
-            s.tA[c][k] = (r < nx) ? A[r + k * nx] : 0.;
-            s.tV[c][k] = (r < nu) ? V[r + k * nu] : 0.;
+        if (which & 1) {
+            SPK_UNROLL for (int k = 0; k < nx; ++k) {
+                s.tW[c][k] = (r < nx) ? W[r + k * nx] : 0.;
+                s.tV[c][k] = (r < nu) ? V[r + k * nu] : 0.;
+            }
         }
-        SPK_UNROLL for (int k = 0; k < nu; ++k) s.tB[c][k] = (r < nx) ? B[r + k * nx] : 0.;
+        if (which & 2) {
+            SPK_UNROLL for (int k = 0; k < nx; ++k) s.tA[c][k] = (r < nx) ? A[r + k * nx] : 0.;
+            SPK_UNROLL for (int k = 0; k < nu; ++k) s.tB[c][k] = (r < nx) ? B[r + k * nx] : 0.;
+        }
     }
-    const MatPtr K = SW + dm.sw_oK;
-    SPK_UNROLL for (int k = 0; k < nx; ++k) s.tK[k] = (r < nu) ? K[r + k * nu] : 0.;
+    if (which & 2) {
+        const MatPtr K = SW + dm.sw_oK;
+        SPK_UNROLL for (int k = 0; k < nx; ++k) s.tK[k] = (r < nu) ? K[r + k * nu] : 0.;
+    }
 }
 
 template <class P>

@@ -135,7 +135,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // register-resident variant of the team sweep: rows of this thread's node in registers, loaded before phase A so that
     // their latency hides behind it
     const bool team_reg = P::REGROWS && team > 0 && a.team_reg && (team * nl_grp <= x.nthreads());
-    if (team_reg) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s); });
+    if (team_reg) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s, MODE == MODE_SUB_BA ? 2 : 3); });
 
     // Every first touch of data another kernel wrote is a cold miss (~1.5-2 us: the writer sat on another XCD).  Issue the
     // matrix-row loads above and the sweep inputs staged here in registers back to back, before waiting for any of them.
@@ -458,6 +458,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 #ifdef SPOCK_HOST_EMU
         if (std::getenv("SPOCK_EMU_NO_V2FIX")) v2x = nullptr;   // negative test: the emulation must expose the hazard the fix removes
 #endif
+        if (team_reg && !crown_blk) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s, 1); });
         phase_a(zo, vo, zn, v2x);
         if (crown_blk) return;
         stamp();

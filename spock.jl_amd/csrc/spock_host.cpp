@@ -143,7 +143,8 @@ int choose_split_stage(int N, int d, int nx) {
 
 bool team_local_applies(const Dims &dm) {
     if (std::getenv("SPOCK_AMD_NO_TEAM_LOCAL")) return false;
-    return (dm.nx > 8 || dm.nu > 8) && dm.diag_costs && dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1 && !dm.risk_has_soc;
+    const bool big = (dm.nx > 8 || dm.nu > 8) || std::getenv("SPOCK_AMD_FORCE_TEAM_LOCAL");   // (the override is for experiments)
+    return big && dm.diag_costs && dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1 && !dm.risk_has_soc;
 }
 
 LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {

@@ -134,8 +134,9 @@ int launch_group(int mode, const KArgs &a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const Dims &dm = a.dm;
     const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
+    static const bool force_dyn = std::getenv("SPOCK_AMD_FORCE_DYN") != nullptr;   // experiments: run-time-dimension kernels for every shape
 #define X(a_, b_, c_, e_)                                                                      \
-    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                                \
+    if (!force_dyn && dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                  \
         return cm == 2 ? launch_variant<StaticDims<a_, b_, c_, e_, 2>>(mode, a, st) : cm == 1 ? launch_variant<StaticDims<a_, b_, c_, e_, 1>>(mode, a, st)    \
                              : launch_variant<StaticDims<a_, b_, c_, e_, 0>>(mode, a, st);
     SPOCK_STATIC_SHAPES(X)

@@ -20,6 +20,7 @@ int event_create(void **e);
 int event_destroy(void *e);
 int event_record(void *e, void *s);
 int event_elapsed(float *ms, void *e0, void *e1);
+bool timing_supported();   // events measure device time (false in the host emulation)
 // stream capture of a launch sequence into an executable graph
 bool graphs_supported();
 int capture_begin(void *s);

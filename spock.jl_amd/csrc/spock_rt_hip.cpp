@@ -21,6 +21,7 @@ int event_destroy(void *e) { RT(hipEventDestroy((hipEvent_t)e)); }
 int event_record(void *e, void *s) { RT(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); }
 int event_elapsed(float *ms, void *e0, void *e1) { RT(hipEventElapsedTime(ms, (hipEvent_t)e0, (hipEvent_t)e1)); }
 bool graphs_supported() { return true; }
+bool timing_supported() { return true; }
 int capture_begin(void *s) { RT(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal)); }
 int capture_end(void *s, void **exec) {
     hipGraph_t g = nullptr;

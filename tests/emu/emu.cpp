@@ -247,6 +247,7 @@ int event_elapsed(float *ms, void *e0, void *e1) {
     return 0;
 }
 bool graphs_supported() { return false; }
+bool timing_supported() { return false; }
 int capture_begin(void *) { return 1; }
 int capture_end(void *, void **) { return 1; }
 int graph_launch(void *, void *) { return 1; }

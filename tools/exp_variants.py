@@ -22,5 +22,6 @@ for lib in libs:
     name = "default" if lib is None else os.path.basename(lib)
     if only and not any(o in name for o in only): continue
     print(name, flush=True)
-    for B in (256, 1):
-        run(lib, B)
+    for nu in (2, 5):
+        for B in (256, 1):
+            run(lib, B, nu=nu)
