@@ -115,6 +115,9 @@ def main():
     split = model.sizes.split_stage > 0
     dom = max(("sub_a", "crown", "sub_b", "full"), key=lambda k: prof[k][0] * (prof[k][1] > 0))
     dom_ms = prof[dom][0]
+    fused = bool(model.sizes.fused_iteration)
+    if fused:   # "sub_b" is then the fused SUB_BA kernel: phase B of iteration k + phase A / backward sweep of k + 1 = one whole iteration
+        bytes_["sub_b"] = bytes_["cp_iteration"]
     dom_bytes = B * (bytes_[dom] if dom in bytes_ else bytes_["cp_iteration"])
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     # measured HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come
@@ -124,11 +127,11 @@ def main():
     for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         f = os.path.join(ROOT, "profiles", rnd, f"pmc_b{B}_summary.json")
         if os.path.exists(f):
-            k = json.load(open(f)).get("kernels", {}).get(dom)
+            k = json.load(open(f)).get("kernels", {}).get("sub_ba" if (fused and dom == "sub_b") else dom)
             if k:
                 traffic = k["hbm_bytes_per_launch_corrected"]
             break
-    roofline = {"bound": "hbm", "kernel": {"sub_a": "spock_group_kernel<MODE_SUB_A>", "sub_b": "spock_group_kernel<MODE_SUB_B>",
+    roofline = {"bound": "hbm", "kernel": {"sub_a": "spock_group_kernel<MODE_SUB_A>", "sub_b": "spock_group_kernel<MODE_SUB_BA>" if fused else "spock_group_kernel<MODE_SUB_B>",
                                              "crown": "spock_group_kernel<MODE_CROWN>", "full": "spock_group_kernel<MODE_FULL>"}[dom],
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
@@ -143,7 +146,7 @@ def main():
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "server_heat nx=5 nu=2 d=2, 4096 leaves (reference N=13), CP iteration incl. termination residuals",
                       "instances_per_gpu": B, "iterations_per_step": M, "nz": flat.nz, "nv": flat.nv,
-                      "split_stage": int(model.sizes.split_stage), "algorithm": "CP",
+                      "split_stage": int(model.sizes.split_stage), "algorithm": "CP", "fused_iteration": fused,
                       "parallelism": f"{n_gpus} x {B} independent instances, RCCL all_gather of results only"},
            "roofline": roofline}
 

@@ -112,6 +112,7 @@ typedef struct {
     int32_t z_x, z_u, z_s, z_tau, z_y;
     int32_t v1, v2, v3, v4, v5, v6, v7, v11, v12, v13, v14;
     int32_t split_stage, n_subtrees, graph_iters;
+    int32_t fused_iteration;  /* 1: a CP iteration runs as CROWN + SUB_BA (chosen per handle by timing), 0: SUB_A + CROWN + SUB_B / whole-tree kernel */
 } spock_sizes_t;
 
 /* build_model(scen_tree, cost, dynamics, rms, constraints, SolverOptions(alg, nothing))

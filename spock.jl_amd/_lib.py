@@ -43,7 +43,7 @@ class Sizes(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
                 ("n", "n_nonleaf", "n_leaf", "nz", "nv", "batch", "z_x", "z_u", "z_s", "z_tau", "z_y",
                  "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v11", "v12", "v13", "v14",
-                 "split_stage", "n_subtrees", "graph_iters")]
+                 "split_stage", "n_subtrees", "graph_iters", "fused_iteration")]
 
 
 # every symbol include/spock_amd.h declares: (restype, argtypes)

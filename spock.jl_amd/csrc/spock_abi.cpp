@@ -461,6 +461,7 @@ int spock_sizes(spock_handle_t h, spock_sizes_t *s) {
     s->v1 = 0; s->v2 = dm.o2; s->v3 = dm.o3; s->v4 = dm.o4; s->v5 = dm.o5; s->v6 = dm.o6; s->v7 = dm.o7;
     s->v11 = dm.o11; s->v12 = dm.o12; s->v13 = dm.o13; s->v14 = dm.o14;
     s->split_stage = dm.t0; s->n_subtrees = dm.nsub; s->graph_iters = h->graph_iters;
+    s->fused_iteration = h->fused ? 1 : 0;
     return SPOCK_OK;
 }
 

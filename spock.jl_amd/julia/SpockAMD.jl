@@ -68,7 +68,7 @@ function build_gpu_model(scen_tree, cost, dynamics, rms, constraints, algorithm:
         o = SpockOptions(algorithm, device, 1, 0, NaN, 0, 0)
         check(ccall((:spock_create, libspock), Cint, (Ref{SpockProblem}, Ref{SpockOptions}, Ref{Ptr{Cvoid}}), p, o, h))
     end
-    sizes = zeros(Cint, 25)
+    sizes = zeros(Cint, 26)
     check(ccall((:spock_sizes, libspock), Cint, (Ptr{Cvoid}, Ptr{Cint}), h[], sizes))
     nz, nv = Int(sizes[4]), Int(sizes[5])
     model = GPU_SPOCK(h[], GPUSolverState(nz, nv, algorithm == 1 ? 10. : 3.28, zeros(nz), zeros(nv)), nothing, nothing)
