@@ -415,7 +415,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         for (int k = 0; k < 3; ++k) if ((e = dev_alloc(h, &h->d_z[k], B * dm.nz))) return bail(e, "hipMalloc(state)");
         for (int k = 0; k < 2; ++k) if ((e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
         if ((e = dev_alloc(h, &h->d_v2x, B * (size_t)dm.nsub))) return bail(e, "hipMalloc(state)");
-        h->fused = dm.t0 > 0 && !launch_geometry(MODE_SUB_B, dm, h->batch).team_local;
+        h->fused = dm.t0 > 0;
     } else {
         const size_t nr = (size_t)dm.nz + dm.nv;
         for (int k = 0; k < 10; ++k) if ((e = dev_alloc(h, &h->s_vec[k], B * nr))) return bail(e, "hipMalloc(SP state)");

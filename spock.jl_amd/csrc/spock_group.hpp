@@ -191,7 +191,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     const int tm = tid / TT, r = tid - tm * TT;
                     if (tm >= nteams) return;
                     const TeamNode tn = team_node(dm, d, base + tm, nl_grp, root_stage, root_pos, stages, crown);
-                    ta_p1(p, dm, M, zi, vi, zout, tn, r, TT, tscr + tm * tscr_stride, crown_blk ? nullptr : tl.XL, gamma, flags, s.tlr);
+                    ta_p1(p, dm, M, zi, vi, zout, tn, r, TT, tscr + tm * tscr_stride, crown_blk ? nullptr : tl.XL, gamma, flags, s.tlr, v2x);
                 });
                 x.barrier();
                 if (!(flags & F_RAW_LT))
@@ -455,6 +455,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 if (s.active && s.kids_gleaf)
                     for (int c = 0; c < d; ++c) v2x[s.pos * d + c] = risk_v2_only(p, dm, M, z, v, zo, s.c0 + c, ps);
             });
+        if (crown_blk && team_local) x.barrier();   // other lanes of the node's team read them
 #ifdef SPOCK_HOST_EMU
         if (std::getenv("SPOCK_EMU_NO_V2FIX")) v2x = nullptr;   // negative test: the emulation must expose the hazard the fix removes
 #endif

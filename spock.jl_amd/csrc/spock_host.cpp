@@ -199,6 +199,9 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
         if ((team_doubles + scr) * 8 + tail <= budget) { g.team_local = 1; team_doubles += scr; g.threads = thr; }
     }
     if (g.team_local) {}
+    // (Lane-team node-local phases on the register-resident sweep's (node, element) thread mapping were tried for the
+    // compile-time shapes in the single-instance regime: no gain -- phase B is bound by its two cold memory round trips
+    // either way -- so those shapes keep one thread per node in the node-local phases.)
     else if (g.team_reg) g.threads = r64(g.team * nl);
     else if (g.team) {
         int want = r64(g.team * widest);

@@ -95,7 +95,7 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
                            : mode == MODE_SUB_A ? (const void *)spock_group_kernel<P, MODE_SUB_A>
                            : mode == MODE_CROWN ? (const void *)spock_group_kernel<P, MODE_CROWN>
                            : mode == MODE_SUB_B ? (const void *)spock_group_kernel<P, MODE_SUB_B>
-                           : mode == MODE_SUB_BA ? (const void *)spock_group_kernel<P, P::TEAMLOCAL ? MODE_SUB_B : MODE_SUB_BA>
+                           : mode == MODE_SUB_BA ? (const void *)spock_group_kernel<P, MODE_SUB_BA>
                                                 : (const void *)spock_group_kernel<P, MODE_FINALIZE>;
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
@@ -109,9 +109,7 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
         case MODE_SUB_B: hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_B>), grid, block, lds, st, a); break;
         case MODE_FINALIZE: hipLaunchKernelGGL((spock_group_kernel<P, MODE_FINALIZE>), grid, block, lds, st, a); break;
         case MODE_SUB_BA:
-            // the fused kernel exists for the per-thread node-local phases only
-            if constexpr (P::TEAMLOCAL) return (int)hipErrorInvalidConfiguration;
-            else hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_BA>), grid, block, lds, st, a);
+            hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_BA>), grid, block, lds, st, a);
             break;
         default: return (int)hipErrorInvalidValue;
     }

@@ -19,7 +19,7 @@ namespace spock {
 
 struct TeamNode {   // the node a team works on in the current round
     int li, lvl, pos, node, c0, stage;
-    bool active, kids_leaf;
+    bool active, kids_leaf, kids_gleaf;
 };
 
 SPK_DEV TeamNode team_node(const Dims &dm, int d, int li, int nl_grp, int root_stage, int root_pos, int stages, bool crown) {
@@ -32,7 +32,8 @@ SPK_DEV TeamNode team_node(const Dims &dm, int d, int li, int nl_grp, int root_s
     t.node = dm.first[root_stage + lvl] + root_pos * cnt + t.pos;
     t.c0 = t.node * d + 1;
     t.stage = root_stage + lvl;
-    t.kids_leaf = (lvl == stages - 2) && !crown && (root_stage + stages == dm.N);
+    t.kids_gleaf = (lvl == stages - 2);
+    t.kids_leaf = t.kids_gleaf && !crown && (root_stage + stages == dm.N);
     return t;
 }
 
@@ -44,7 +45,7 @@ SPK_DEV int team_scratch_doubles(int nu, int m, int d, int T) { return m + nu + 
 template <class P>
 SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z, const double *__restrict__ v,
                    double *__restrict__ zo, const TeamNode &t, int r, int T, double *S, double *XL, double gamma, unsigned flags,
-                   TLReg<P> &g) {
+                   TLReg<P> &g, const double *v2x = nullptr) {
     if (!t.active) return;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), nxu = nx + nu, m = ny + 2 * d;
     const int i = t.node;
@@ -54,11 +55,11 @@ SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
     double *vec = S, *ubs = S + m;
     if (r < nx) {   // x_i[r] <- v7 + sum_j sqrtQ v3_j  (implicit_l.jl:351-373), diagonal sqrtQ
         double acc = v[dm.o7 + i * nxu + r];
-        for (int c = 0; c < d; ++c) acc += SQ[r + r * nx] * v[dm.o3 + (t.c0 + c - 1) * nx + r];
+        SPK_UNROLL for (int c = 0; c < d; ++c) acc += SQ[r + r * nx] * v[dm.o3 + (t.c0 + c - 1) * nx + r];
         g.xb = mg * acc + z[dm.zx + i * nx + r];
         if (raw) zo[dm.zx + i * nx + r] = g.xb;
         if (t.kids_leaf)   // leaves: x_j <- v14 + sqrtQN v11 (implicit_l.jl:376-396); q_leaf = -xbar_leaf goes to the sweep
-            for (int c = 0; c < d; ++c) {
+            SPK_UNROLL for (int c = 0; c < d; ++c) {
                 const int j = t.c0 + c, li = j - dm.nn;
                 const double xl = mg * (v[dm.o14 + li * nx + r] + SN[r + r * nx] * v[dm.o11 + li * nx + r]) + z[dm.zx + j * nx + r];
                 if (raw) zo[dm.zx + j * nx + r] = xl;
@@ -67,7 +68,7 @@ SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
     }
     if (r < nu) {   // u_i[r] (implicit_l.jl:399-420)
         double acc = v[dm.o7 + i * nxu + nx + r];
-        for (int c = 0; c < d; ++c) acc += SR[r + r * nu] * v[dm.o4 + (t.c0 + c - 1) * nu + r];
+        SPK_UNROLL for (int c = 0; c < d; ++c) acc += SR[r + r * nu] * v[dm.o4 + (t.c0 + c - 1) * nu + r];
         g.ub = mg * acc + z[dm.zu + i * nu + r];
         if (raw) zo[dm.zu + i * nu + r] = g.ub; else ubs[r] = g.ub;
     }
@@ -76,7 +77,8 @@ SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
         if (e < ny) val = mg * (v[i * ny + e] - bb[e] * v[dm.o2 + i]) + z[dm.zy + i * ny + e];
         else if (e < ny + d) {
             const int j = t.c0 + (e - ny);
-            const double ls = (j < dm.nn) ? v[dm.o2 + j] : 0.5 * v[dm.o12 + (j - dm.nn)] + 0.5 * v[dm.o13 + (j - dm.nn)];
+            const double ls = (v2x && t.kids_gleaf) ? v2x[t.pos * d + (e - ny)]   // crown workgroup of the fused B+A kernel
+                              : (j < dm.nn) ? v[dm.o2 + j] : 0.5 * v[dm.o12 + (j - dm.nn)] + 0.5 * v[dm.o13 + (j - dm.nn)];
             val = mg * ls + z[dm.zs + j];
         } else {
             const int j = t.c0 + (e - ny - d);
@@ -143,18 +145,18 @@ SPK_DEV void tb_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
     }
     red[0 * T + r] = pb0; red[1 * T + r] = pb1;
     double sq[2 * P::MAXD];
-    for (int c = 0; c < 2 * d; ++c) sq[c] = 0.;
+    SPK_UNROLL for (int c = 0; c < 2 * d; ++c) sq[c] = 0.;
     if (r < nx) {
         const double xi = xsrc[r], zi = z[dm.zx + i * nx + r];
         g.wx = wz ? xi : 2. * xi + -1. * zi; g.dzx = xi - zi; g.xb = xi;
-        for (int c = 0; c < d; ++c) {   // v3_j = sqrtQ x_i (implicit_l.jl:226-235)
+        SPK_UNROLL for (int c = 0; c < d; ++c) {   // v3_j = sqrtQ x_i (implicit_l.jl:226-235)
             const int jn = t.c0 + c - 1;
             g.t3[c] = (sg * (SQ[r + r * nx] * g.wx) + v[dm.o3 + jn * nx + r]) * isg;
             g.l3[c] = SQ[r + r * nx] * g.dzx;
             sq[c] += g.t3[c] * g.t3[c];
         }
         if (t.kids_leaf)
-            for (int c = 0; c < d; ++c) {   // v11 = sqrtQN x_leaf, v14 = x_leaf (implicit_l.jl:288-317)
+            SPK_UNROLL for (int c = 0; c < d; ++c) {   // v11 = sqrtQN x_leaf, v14 = x_leaf (implicit_l.jl:288-317)
                 const int j = t.c0 + c, li = j - dm.nn;
                 const double xl = xlsrc[c * xl_stride + r], zk = z[dm.zx + j * nx + r];
                 g.wl[c] = wz ? xl : 2. * xl + -1. * zk; g.dl[c] = xl - zk;
@@ -167,14 +169,14 @@ SPK_DEV void tb_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
     if (r < nu) {
         const double ui = usrc[r], zi = z[dm.zu + i * nu + r];
         g.wu = wz ? ui : 2. * ui + -1. * zi; g.dzu = ui - zi; g.ub = ui;
-        for (int c = 0; c < d; ++c) {   // v4_j = sqrtR u_i (implicit_l.jl:239-248)
+        SPK_UNROLL for (int c = 0; c < d; ++c) {   // v4_j = sqrtR u_i (implicit_l.jl:239-248)
             const int jn = t.c0 + c - 1;
             g.t4[c] = (sg * (SR[r + r * nu] * g.wu) + v[dm.o4 + jn * nu + r]) * isg;
             g.l4[c] = SR[r + r * nu] * g.dzu;
             sq[c] += g.t4[c] * g.t4[c];
         }
     }
-    for (int c = 0; c < 2 * d; ++c) red[(2 + c) * T + r] = sq[c];
+    SPK_UNROLL for (int c = 0; c < 2 * d; ++c) red[(2 + c) * T + r] = sq[c];
 }
 
 // phase B, part 2: finish the Moreau step (prox_h_conj!), store vbar, accumulate the residual maxima
@@ -241,7 +243,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
         m2 = spk_max_nan(m2, fabs(lxu));
     }
     // ---- per child: (v6; v3, v4, v5) in SOC(nx + nu + 2)   (implicit_l.jl:854-900, :928-933)
-    for (int c = 0; c < d; ++c) {
+    SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = t.c0 + c, jn = j - 1;
         const double zbt = zb[dm.zt + jn], zt_ = z[dm.zt + jn];
         const double wt = wz ? zbt : 2. * zbt + -1. * zt_, dzt = zbt - zt_;
@@ -360,7 +362,7 @@ SPK_DEV void tlop(const P &p, const Dims &dm, MatPtr M, const double *__restrict
             double lt = b7;
             if (A) sum += av[dm.o7 + i * nxu + r] * (b7 - sigma * bx);
             m2 = spk_max_nan(m2, fabs(bx + nis * b7));
-            for (int c = 0; c < d; ++c) {
+            SPK_UNROLL for (int c = 0; c < d; ++c) {
                 const int jn = t.c0 + c - 1;
                 const double b3 = bv[dm.o3 + jn * nx + r], l3 = SQ[r + r * nx] * bx;
                 lt += SQ[r + r * nx] * b3;
@@ -384,7 +386,7 @@ SPK_DEV void tlop(const P &p, const Dims &dm, MatPtr M, const double *__restrict
             double lt = b7;
             if (A) sum += av[dm.o7 + i * nxu + nx + r] * (b7 - sigma * bu);
             m2 = spk_max_nan(m2, fabs(bu + nis * b7));
-            for (int c = 0; c < d; ++c) {
+            SPK_UNROLL for (int c = 0; c < d; ++c) {
                 const int jn = t.c0 + c - 1;
                 const double b4 = bv[dm.o4 + jn * nu + r], l4 = SR[r + r * nu] * bu;
                 lt += SR[r + r * nu] * b4;
@@ -410,7 +412,7 @@ SPK_DEV void tlop(const P &p, const Dims &dm, MatPtr M, const double *__restrict
             if (A) sum += az[dm.zs + i] * (bs - gamma * b2v) + av[dm.o2 + i] * (b2v - sigma * l2);
             m1 = spk_max_nan(m1, fabs(b2v + nig * bs));
             m2 = spk_max_nan(m2, fabs(l2 + nis * b2v));
-            for (int c = 0; c < d; ++c) {
+            SPK_UNROLL for (int c = 0; c < d; ++c) {
                 const int j = t.c0 + c, jn = j - 1;
                 const double bt = bz[dm.zt + jn], b5 = bv[dm.o5 + jn], b6 = bv[dm.o6 + jn];
                 const double lt = 0.5 * b5 + 0.5 * b6, l56 = 0.5 * bt;

@@ -82,7 +82,7 @@ static int launch_variant(int mode, const KArgs &a_in) {
         case MODE_CROWN: run_blocks<P, MODE_CROWN>(a, gx, thr); break;
         case MODE_SUB_B: run_blocks<P, MODE_SUB_B>(a, gx, thr); break;
         case MODE_FINALIZE: run_blocks<P, MODE_FINALIZE>(a, gx, thr); break;
-        case MODE_SUB_BA: if constexpr (P::TEAMLOCAL) return 9; else run_blocks<P, MODE_SUB_BA>(a, gx, thr); break;
+        case MODE_SUB_BA: run_blocks<P, MODE_SUB_BA>(a, gx, thr); break;
         default: return 1;
     }
     return 0;

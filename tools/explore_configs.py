@@ -18,7 +18,7 @@ def run(name, specs, L=None, iters=60, check=True):
         rng = np.random.default_rng(0); z = rng.standard_normal(flat.nz); v = rng.standard_normal(flat.nv)
         zo, vo = m.T(z, v, 0.3, 0.3, x0); zr, vr = o.T(z, v, 0.3, 0.3, x0)
         err = max(np.max(np.abs(zo - zr)) / max(1, np.max(np.abs(zr))), np.max(np.abs(vo - vr)) / max(1, np.max(np.abs(vr))))
-    print(f"{name}: n={flat.n} nz={flat.nz} nv={flat.nv} split={m.sizes.split_stage} build {tb:.2f}s  {r['solve_ms']/r['iterations']*1e3:9.1f} us/iter  T err {err:.1e}", flush=True)
+    print(f"{name}: n={flat.n} nz={flat.nz} nv={flat.nv} split={m.sizes.split_stage} fused={m.sizes.fused_iteration} build {tb:.2f}s  {r['solve_ms']/r['iterations']*1e3:9.1f} us/iter  T err {err:.1e}", flush=True)
     m.close()
 
 run("cfg1 N=10 nx=5 d=2", S.get_server_heat_specs(10, 5, 2))

@@ -6,7 +6,7 @@ import spock_jl_amd as S
 from spock_jl_amd import _lib
 
 specs = S.get_server_heat_specs(13, 5, 2, nu=2)
-for B in (1, 64):
+for B in (1, 256):
     m = S.build_model(*specs, batch=B, split_stage=6, max_iter=100)
     S.solve_model(m, np.full((B, 5), 0.1), tol=0.0)
     os.environ["SPOCK_AMD_DEBUG_FLAGS"] = "512"
