@@ -33,6 +33,7 @@ struct spock_handle_s {
     void *stream = nullptr, *ev0 = nullptr, *ev1 = nullptr, *graph = nullptr;
     // device memory
     double *d_mats = nullptr, *d_z[3] = {nullptr, nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}, *d_v2x = nullptr;
+    bool sp_fused = false;   // SP: the inner products with the residuals come out of phase B instead of out of LOP kernels
     bool fused = false;   // CP iteration = CROWN + SUB_BA (after one SUB_A) instead of SUB_A + CROWN + SUB_B
     double *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_partials = nullptr, *d_x0 = nullptr, *d_hist = nullptr;
     Ctl *d_ctl = nullptr;
@@ -220,25 +221,35 @@ SpArgs make_sp_args(spock_handle_s *h, int op) {
     a.nr = (long)dm.nz + dm.nv;
     a.n_partF = sp_flat_blocks(a.nr); a.n_partL = sp_lop_blocks(dm);
     a.batch = h->batch; a.op = op;
+    a.partG = h->d_partials; a.n_partG = dm.t0 > 0 ? dm.nsub + 1 : 1; a.fused_lop = h->sp_fused ? 1 : 0;
     return a;
 }
 
 // T(in) -> out on the concatenated z|v vectors with the CP kernels (no CP termination logic: F_SP)
-int launch_sp_T(spock_handle_s *h, double *in, double *out) {
+int launch_sp_T(spock_handle_s *h, double *in, double *out, int sp_mode = 0, const double *dir = nullptr) {
     const Dims &dm = h->bp.dm;
     KArgs a = make_args(h, false, 0, F_SP);
+    a.sp_mode = h->sp_fused ? sp_mode : 0; a.dir = dir;
     a.z_in = in; a.v_in = in + dm.nz; a.z_out = out; a.v_out = out + dm.nz;
     a.stride_z = a.stride_v = (long)dm.nz + dm.nv;
     a.hist = nullptr; a.hist_cap = 0;
-    if (dm.t0 == 0) return launch_group(MODE_FULL, a, h->stream);
+    if (dm.t0 == 0) return launch_group(a.sp_mode ? MODE_FULL_SP : MODE_FULL, a, h->stream);
     int e = launch_group(MODE_SUB_A, a, h->stream);
     if (!e) e = launch_group(MODE_CROWN, a, h->stream);
-    if (!e) e = launch_group(MODE_SUB_B, a, h->stream);
+    if (!e) e = launch_group(a.sp_mode ? MODE_SUB_B_SP : MODE_SUB_B, a, h->stream);
     return e;
 }
 
 int launch_sp_iteration(spock_handle_s *h) {
-    int e = launch_sp_T(h, h->s_vec[SV_Z], h->s_vec[SV_ZB]);
+    int e = launch_sp_T(h, h->s_vec[SV_Z], h->s_vec[SV_ZB], 1);
+    if (h->sp_fused) {   // <r, P r>, <rt, P rt>, <rt, P d> come out of phase B of the two T evaluations: 15 launches
+        const int seq1[] = {SP_FLAT1, SP_CTL_A, SP_FLAT2, SP_CTL_B, SP_FLAT3};
+        for (int op : seq1) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
+        if (!e) e = launch_sp_T(h, h->s_vec[SV_W], h->s_vec[SV_WB], 2, h->s_vec[SV_D]);
+        const int seq2[] = {SP_CTL_C, SP_FLAT5, SP_LOP_DP, SP_CTL_D};
+        for (int op : seq2) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
+        return e;
+    }
     const int seq1[] = {SP_FLAT1, SP_LOP_R, SP_CTL_A, SP_FLAT2, SP_CTL_B, SP_FLAT3};
     for (int op : seq1) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
     if (!e) e = launch_sp_T(h, h->s_vec[SV_W], h->s_vec[SV_WB]);
@@ -435,6 +446,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     for (auto &c : h->h_ctl) c.done = 1;
     if ((e = rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream))) return bail(e, "upload");
     if (alg == SPOCK_ALG_CP && h->fused && (e = choose_cp_sequence(h))) return bail(e, "timing the CP kernel sequences");
+    if (alg == SPOCK_ALG_SP) h->sp_fused = !launch_geometry(dm.t0 > 0 ? MODE_SUB_B : MODE_FULL, dm, h->batch).team_local && !std::getenv("SPOCK_AMD_SP_LOP");
     if (alg == SPOCK_ALG_SP && (e = sp_init_state(h))) return bail(e, "SP state initialisation");
     if ((e = rt::sync(h->stream))) return bail(e, "hipStreamSynchronize");
     *out = h;

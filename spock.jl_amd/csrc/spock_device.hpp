@@ -430,16 +430,12 @@ SPK_DEV void team_reg_init(const P &p, const Dims &dm, MatPtr M, int root_stage,
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const MatPtr W = SW + dm.sw_oW + c * nx * nx, V = SW + dm.sw_oV + c * nu * nx, A = SW + dm.sw_oABK + c * nx * nx;
         const MatPtr B = M + dm.mB + slot_event(c, d) * nx * nu;
-        if (which & 1) {
-            SPK_UNROLL for (int k = 0; k < nx; ++k) {
-                s.tW[c][k] = (r < nx) ? W[r + k * nx] : 0.;
-                s.tV[c][k] = (r < nu) ? V[r + k * nu] : 0.;
-            }
+        SPK_UNROLL for (int k = 0; k < nx; ++k) {   // (this load order is the one the register allocator copes with best)
+            if (which & 1) s.tW[c][k] = (r < nx) ? W[r + k * nx] : 0.;
+            if (which & 2) s.tA[c][k] = (r < nx) ? A[r + k * nx] : 0.;
+            if (which & 1) s.tV[c][k] = (r < nu) ? V[r + k * nu] : 0.;
         }
-        if (which & 2) {
-            SPK_UNROLL for (int k = 0; k < nx; ++k) s.tA[c][k] = (r < nx) ? A[r + k * nx] : 0.;
-            SPK_UNROLL for (int k = 0; k < nu; ++k) s.tB[c][k] = (r < nx) ? B[r + k * nx] : 0.;
-        }
+        if (which & 2) { SPK_UNROLL for (int k = 0; k < nu; ++k) s.tB[c][k] = (r < nx) ? B[r + k * nx] : 0.; }
     }
     if (which & 2) {
         const MatPtr K = SW + dm.sw_oK;
@@ -489,6 +485,7 @@ SPK_DEV void fwd_team_reg(const P &p, int stages, const TeamLds &L, const TState
 // F_NO_SWEEP), z/v = the input iterate, vo = vbar.  mx[0..2] accumulate |xi_1|, |xi_2|, |xi| maxima.
 struct ProxScal {
     double sigma, inv_sigma;                     // 1/sigma: arg/sigma of prox_h_conj! as a multiplication
+    double gamma;
     double inv_sigma_neg, inv_gamma_neg;         // -1/sigma, -1/gamma as the reference forms them (cp.jl:73-75)
     bool want_xi;                                // LOG-mode CP: xi = xi_1 + L' xi_2 (cp.jl:83-86)
 };
@@ -514,15 +511,33 @@ SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, const double *
     return ps.sigma * (t2 - p2);
 }
 
-template <class P>
+// SPM (SP driver, spock_sp.hpp): the inner products of run_sp! that involve the residual r = (z, v) - T(z, v) of THIS
+// evaluation, accumulated where its pieces are at hand instead of in a separate pass that applies L and L' again.
+// With dz = zbar - z, dv = vbar - v and the termination residuals xi_1 = L'dv - dz/gamma, xi_2 = L dz - dv/sigma:
+//   <r, P r> = sum_z dz (dz - gamma L'dv) + sum_v dv (dv - sigma L dz) = -gamma sum_z dz xi_1 - sigma sum_v dv xi_2
+//   <r, P d> = -sum_z d_z (dz - sigma L'dv) - sum_v d_v (dv - gamma L dz)        (implicit_l.jl:485-516)
+//   SPM 1: sp[0] += sum_z dz xi_1, sp[1] += sum_v dv xi_2;   SPM 2: also sp[2] += <r, P d> with d = (dirz, dirv)
+template <class P, int SPM = 0>
 SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
                      const double *__restrict__ v, const double *zb, double *__restrict__ vo, TState<P> &s,
-                     const ProxScal &ps, unsigned flags, double *mx) {
+                     const ProxScal &ps, unsigned flags, double *mx, double *sp = nullptr, const double *dirz = nullptr,
+                     const double *dirv = nullptr) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu;
     const double sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0, wx = ps.want_xi;
     double m1 = mx[0], m2 = mx[1], m3 = mx[2];
+    double sp_z = 0., sp_v = 0., sp_d = 0.;
+    const double gm = ps.gamma;
+    // one z entry (index iz, dz, xi_1) / one v entry (index iv, dv, xi_2) of the sums above
+    auto acc_z = [&](int iz, double dz, double x1) {
+        if (SPM >= 1) sp_z += dz * x1;
+        if (SPM == 2) sp_d -= dirz[iz] * (dz - sg * (x1 - nig * dz));
+    };
+    auto acc_v = [&](int iv, double dv, double x2) {
+        if (SPM >= 1) sp_v += dv * x2;
+        if (SPM == 2) sp_d -= dirv[iv] * (dv - gm * (x2 - nis * dv));
+    };
     if (flags & F_NO_SWEEP) {
         SPK_UNROLL for (int k = 0; k < nx; ++k) s.xb[k] = zb[dm.zx + i * nx + k];
         SPK_UNROLL for (int k = 0; k < nu; ++k) s.ub[k] = zb[dm.zu + i * nu + k];
@@ -615,6 +630,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         const double dv2 = nv2 - v[dm.o2 + i];
         const double x2 = (dzs - bdz) + nis * dv2;          // xi_2 on v2
         m2 = spk_max_nan(m2, fabs(x2));
+        acc_v(dm.o2 + i, dv2, x2);
         vo[dm.o2 + i] = nv2;
         SPK_UNROLL for (int k = 0; k < ny; ++k) {
             const double dv1 = pr[k] - v[i * ny + k];
@@ -623,10 +639,12 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
             m2 = spk_max_nan(m2, fabs(x2k));
             const double x1k = (dv1 - bb[k] * dv2) + nig * dzy[k];   // xi_1 on y (implicit_l.jl:423-429)
             m1 = spk_max_nan(m1, fabs(x1k));
+            acc_v(i * ny + k, dv1, x2k); acc_z(dm.zy + i * ny + k, dzy[k], x1k);
             if (wx) m3 = spk_max_nan(m3, fabs((x2k - bb[k] * x2) + x1k));
         }
         const double x1s = dv2 + nig * dzs;                 // xi_1 on s_i (implicit_l.jl:440-442)
         m1 = spk_max_nan(m1, fabs(x1s));
+        acc_z(dm.zs + i, dzs, x1s);
         if (wx) m3 = spk_max_nan(m3, fabs(x2 + x1s));
     }
     // ---- v7 : box on (x_i, u_i)  (implicit_l.jl:275-282, constraints.jl:38-54) ---------------------
@@ -647,6 +665,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
             const double dv = nvv - vin;
             const double x2 = dzv + nis * dv;
             m2 = spk_max_nan(m2, fabs(x2));
+            acc_v(dm.o7 + i * nxu + k, dv, x2);
             if (isx) { ltx[k] = dv; lxx[k] = x2; } else { ltu[k - nx] = dv; lxu[k - nx] = x2; }
         }
     }
@@ -688,6 +707,12 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         vo[dm.o5 + jn] = pj[1 + nxu];
         tt[1 + nxu] = pj[1 + nxu] - v[dm.o5 + jn];
         SPK_UNROLL for (int k = 0; k < len; ++k) { lz[k] = lz[k] + nis * tt[k]; m2 = spk_max_nan(m2, fabs(lz[k])); }
+        if (SPM >= 1) {
+            acc_v(dm.o6 + jn, tt[0], lz[0]);
+            SPK_UNROLL for (int r = 0; r < nx; ++r) acc_v(dm.o3 + jn * nx + r, tt[1 + r], lz[1 + r]);
+            SPK_UNROLL for (int r = 0; r < nu; ++r) acc_v(dm.o4 + jn * nu + r, tt[1 + nx + r], lz[1 + nx + r]);
+            acc_v(dm.o5 + jn, tt[1 + nxu], lz[1 + nxu]);
+        }
         // L' contributions: x_i += sqrtQ dv3, u_i += sqrtR dv4 (implicit_l.jl:365-373, :412-420)
         sym_mv<P, true>(nx, SQ, tt + 1, ltx);
         sym_mv<P, true>(nu, SR, tt + 1 + nx, ltu);
@@ -695,6 +720,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         // xi_1 on tau_j: 0.5 dv5 + 0.5 dv6 - dtau/gamma  (implicit_l.jl:432-437)
         const double x1t = (0.5 * tt[1 + nxu] + 0.5 * tt[0]) + nig * dzt;
         m1 = spk_max_nan(m1, fabs(x1t));
+        acc_z(dm.zt + jn, dzt, x1t);
         if (wx) m3 = spk_max_nan(m3, fabs((0.5 * lz[1 + nxu] + 0.5 * lz[0]) + x1t));
 
         // ---- leaf child: (v13; v11, v12) in SOC(nx+2), v14 in the x box (implicit_l.jl:286-317, :752-810)
@@ -734,6 +760,11 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
             vo[dm.o12 + li] = p3[1 + nx];
             t3[1 + nx] = p3[1 + nx] - v[dm.o12 + li];
             SPK_UNROLL for (int k = 0; k < l2; ++k) { l3[k] = l3[k] + nis * t3[k]; m2 = spk_max_nan(m2, fabs(l3[k])); }
+            if (SPM >= 1) {
+                acc_v(dm.o13 + li, t3[0], l3[0]);
+                SPK_UNROLL for (int r = 0; r < nx; ++r) acc_v(dm.o11 + li * nx + r, t3[1 + r], l3[1 + r]);
+                acc_v(dm.o12 + li, t3[1 + nx], l3[1 + nx]);
+            }
             // v14 and the x_j, s_j residuals: x_leaf = v14 + sqrtQN v11 (implicit_l.jl:376-396)
             double a11[P::MAXNX], b11[P::MAXNX];
             sym_mv<P, false>(nx, SN, t3 + 1, a11);
@@ -749,10 +780,12 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
                 m2 = spk_max_nan(m2, fabs(x2));
                 const double x1 = (dv + a11[r]) + nig * dl[r];
                 m1 = spk_max_nan(m1, fabs(x1));
+                acc_v(dm.o14 + li * nx + r, dv, x2); acc_z(dm.zx + j * nx + r, dl[r], x1);
                 if (wx) m3 = spk_max_nan(m3, fabs((x2 + b11[r]) + x1));
             }
             const double x1s = (0.5 * t3[1 + nx] + 0.5 * t3[0]) + nig * dzs;   // s_leaf (implicit_l.jl:445-448)
             m1 = spk_max_nan(m1, fabs(x1s));
+            acc_z(dm.zs + j, dzs, x1s);
             if (wx) m3 = spk_max_nan(m3, fabs((0.5 * l3[1 + nx] + 0.5 * l3[0]) + x1s));
         }
     }
@@ -760,14 +793,18 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
     SPK_UNROLL for (int k = 0; k < nx; ++k) {
         const double x1 = ltx[k] + nig * dzx[k];
         m1 = spk_max_nan(m1, fabs(x1));
+        acc_z(dm.zx + i * nx + k, dzx[k], x1);
         if (wx) m3 = spk_max_nan(m3, fabs(lxx[k] + x1));
     }
     SPK_UNROLL for (int k = 0; k < nu; ++k) {
         const double x1 = ltu[k] + nig * dzu[k];
         m1 = spk_max_nan(m1, fabs(x1));
+        acc_z(dm.zu + i * nu + k, dzu[k], x1);
         if (wx) m3 = spk_max_nan(m3, fabs(lxu[k] + x1));
     }
     mx[0] = m1; mx[1] = m2; mx[2] = m3;
+    if (SPM >= 1) { sp[0] += sp_z; sp[1] += sp_v; }
+    if (SPM == 2) sp[2] += sp_d;
 }
 
 // ------------------------------------------------------------------------------------------------

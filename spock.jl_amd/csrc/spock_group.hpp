@@ -28,14 +28,22 @@
 
 namespace spock {
 
+#ifdef SPOCK_HOST_EMU
+#define SPK_LAMBDA_INLINE
+#else
+#define SPK_LAMBDA_INLINE __attribute__((always_inline))
+#endif
+
 SPK_DEV int group_threads_dev(int d, int stages) {   // non-leaf nodes of a complete d-ary tree with `stages` stages
     int cnt = 0, lvl = 1;
     for (int t = 0; t < stages - 1; ++t) { cnt += lvl; lvl *= d; }
     return cnt;
 }
 
-template <class P, int MODE, class X>
+template <class P, int MODE_, class X>
 SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
+    constexpr int MODE = (MODE_ == MODE_SUB_B_SP) ? MODE_SUB_B : (MODE_ == MODE_FULL_SP) ? MODE_FULL : MODE_;
+    constexpr bool SP_SUMS = (MODE_ != MODE);   // phase B also accumulates the SP driver's inner products
     const Dims &dm = a.dm;
     const P p(dm);
     const unsigned flags = a.flags;
@@ -135,7 +143,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // register-resident variant of the team sweep: rows of this thread's node in registers, loaded before phase A so that
     // their latency hides behind it
     const bool team_reg = P::REGROWS && team > 0 && a.team_reg && (team * nl_grp <= x.nthreads());
-    if (team_reg) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s, MODE == MODE_SUB_BA ? 2 : 3); });
+    if (team_reg) x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s, MODE == MODE_SUB_BA ? 2 : (MODE == MODE_CROWN ? 1 : 3)); });
 
     // Every first touch of data another kernel wrote is a cold miss (~1.5-2 us: the writer sat on another XCD).  Issue the
     // matrix-row loads above and the sweep inputs staged here in registers back to back, before waiting for any of them.
@@ -170,7 +178,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
     const double gamma = ctl.gamma, sigma = ctl.sigma;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nthr = x.nthreads();
-    auto level_geo = [&](int l, int &lfirst, int &cnt, long &gfirst) {
+    auto level_geo = [&](int l, int &lfirst, int &cnt, long &gfirst) SPK_LAMBDA_INLINE {
         cnt = 1; lfirst = 0;
         for (int k = 0; k < l; ++k) { lfirst += cnt; cnt *= d; }
         gfirst = dm.first[root_stage + l] + (long)root_pos * cnt;
@@ -183,7 +191,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
     // ---- phase A (node-local) on the iterate (zi, vi); its part of zbar goes to zout, c_i / e_i (and the leaves' xbar) to
     //      the thread state or the lane teams' LDS vectors, for the crown's extra workgroup to cbuf
-    auto phase_a = [&](const double *zi, const double *vi, double *zout, const double *v2x) {
+    auto phase_a = [&](const double *zi, const double *vi, double *zout, const double *v2x) SPK_LAMBDA_INLINE {
         if (flags & F_NO_ALOCAL) return;
         if (team_local) {
             for (int base = 0; base < nl_grp; base += nteams) {
@@ -228,7 +236,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
     // ---- S1 backward sweep over the group's levels; the subtree kernels leave q_root and every d_i in global memory
     const bool stores_q = (MODE == MODE_SUB_A || MODE == MODE_SUB_BA);
-    auto backward = [&]() {
+    auto backward = [&]() SPK_LAMBDA_INLINE {
         if (!sweeping || (flags & F_DBG_NO_BWD)) return;
         if (team) {   // lane-team version (all sweep vectors in LDS)
             if (MODE == MODE_CROWN) {   // c_i, e_i of the crown and q of the subtree roots -> LDS
@@ -253,6 +261,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 int lfirst, cnt; long gfirst;
                 level_geo(l, lfirst, cnt, gfirst);
                 if (team_reg) {
+                    // crown: the forward sweep's rows are fetched behind the last backward level, so that the two row sets
+                    // are not live together (with both the (5, 5) crown kernel spills registers)
+                    if (MODE == MODE_CROWN && l == 0)
+                        x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s, 2); });
                     x.each([&](int, TState<P> &s) { if (s.tn_li >= 0 && s.tn_lvl == l) bwd_team_reg(p, stages, tl, s); });
                 } else if (lds_mats) {
                     const double *SW = lm + l * dm.sw_stride;
@@ -309,7 +321,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
     // ---- S1 forward roll-out from the group root; x_i, u_i (and the group leaves' x) go to zbar and the thread state
     const bool loads_d = (MODE == MODE_SUB_B || MODE == MODE_SUB_BA);
-    auto forward = [&]() {
+    auto forward = [&]() SPK_LAMBDA_INLINE {
         if (!sweeping || (flags & F_DBG_NO_FWD)) return;
         const double *xroot = loads_d ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
         const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
@@ -386,14 +398,19 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     };
 
     // ---- phase B (node-local) + residual maxima
-    ProxScal ps;
-    ps.sigma = sigma;
-    ps.inv_sigma = 1. / sigma;
-    ps.inv_sigma_neg = -1. / sigma;
-    ps.inv_gamma_neg = -1. / gamma;
-    ps.want_xi = (ctl.log_mode == 2 && ctl.alg == 1);
-    auto phase_b = [&]() {
+    auto make_ps = [&]() {
+        ProxScal ps;
+        ps.sigma = sigma;
+        ps.inv_sigma = 1. / sigma;
+        ps.inv_sigma_neg = -1. / sigma;
+        ps.inv_gamma_neg = -1. / gamma;
+        ps.gamma = gamma;
+        ps.want_xi = (ctl.log_mode == 2 && ctl.alg == 1);
+        return ps;
+    };
+    auto phase_b = [&]() SPK_LAMBDA_INLINE {
         if (flags & F_NO_BLOCAL) return;
+        const ProxScal ps = make_ps();
         const unsigned bflags = crown_blk ? (flags | F_NO_SWEEP) : flags;   // the crown's x, u come from zbar
         if (team_local) {
             const bool from_zb = (bflags & F_NO_SWEEP) != 0;
@@ -418,16 +435,31 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 x.barrier();
             }
             x.each([&](int tid, TState<P> &s) { x.stash3(tid, s.mx3); });
-        } else {
+        } else if constexpr (!SP_SUMS) {
             x.each([&](int tid, TState<P> &s) {
                 double mx[3] = {0., 0., 0.};
                 if (s.active) b_local(p, dm, M, z, v, zo, vo, s, ps, bflags, mx);
                 x.stash3(tid, mx);
             });
+        } else {   // SP driver: the inner products with the residual of this evaluation ride along (b_local, SPM)
+            const double *dz_ = a.dir ? a.dir + (long)inst * a.stride_z : nullptr;
+            x.each([&](int tid, TState<P> &s) {
+                double mx[3] = {0., 0., 0.}, sp[3] = {0., 0., 0.};
+                if (s.active) {
+                    if (a.sp_mode == 2) b_local<P, 2>(p, dm, M, z, v, zo, vo, s, ps, bflags, mx, sp, dz_, dz_ + dm.nz);
+                    else b_local<P, 1>(p, dm, M, z, v, zo, vo, s, ps, bflags, mx, sp);
+                }
+                x.stash3(tid, mx);
+                x.stash_sum3(tid, sp);
+            });
         }
         const int slot = (MODE == MODE_FULL) ? 0 : g;
         x.reduce3();
         x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + tid] = x.red3(tid); });
+        if (SP_SUMS && !team_local) {
+            x.reduce_sum3();
+            x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + 4 + tid] = x.sum3(tid); });
+        }
         stamp();   // phase B done
     };
 
@@ -450,6 +482,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         x.barrier();
         double *zn = a.z_next + (long)inst * a.stride_z;
         double *v2x = crown_blk ? a.v2x + (long)inst * dm.nsub : nullptr;
+        const ProxScal ps = make_ps();
         if (crown_blk)
             x.each([&](int, TState<P> &s) {
                 if (s.active && s.kids_gleaf)

@@ -149,6 +149,8 @@ bool team_local_applies(const Dims &dm) {
 
 LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     LaunchGeo g;
+    if (mode == MODE_SUB_B_SP) mode = MODE_SUB_B;
+    if (mode == MODE_FULL_SP) mode = MODE_FULL;
     const int d = dm.d, nx = dm.nx, nu = dm.nu;
     auto r64 = [](int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; };
     int stage_sets[2], n_sets = 0;
@@ -173,7 +175,7 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     while (T < nx || T < nu) T *= 2;
     const long mats_bytes = ((long)(max_stages - 1) * dm.sw_stride + (long)d * nx * nu) * 8;
     // 160 KiB of LDS per CU on MI355X; the launcher raises the dynamic-LDS limit of the kernel when more than 64 KiB is used
-    const long budget = 144 * 1024, tail = (4 + 128) * 8;   // reduction scratch + flag + 64 diagnostic clock stamps
+    const long budget = 144 * 1024, tail = (4 + 128 + 32) * 8;   // reduction scratch + flag, 64 diagnostic clock stamps, SP sum reduction
     // Lane teams pay off when a node's mat-vecs are big (measured on MI355X: nx = nu = 20, N = 10: 3058 -> 561 us per
     // iteration).  For the small compile-time shapes (nx <= 8) one thread per node with the vectors in registers and
     // the matrices in SGPRs is as fast per level and keeps workgroups at one wave, which the batched regime needs

@@ -59,7 +59,7 @@ struct Ctl {
     double gamma, sigma, tol;
 };
 
-constexpr int kPartialStride = 4;  // xi1, xi2, xi, unused -- per workgroup
+constexpr int kPartialStride = 8;  // per workgroup: xi1, xi2, xi, - | SP: sum_z dz xi_1, sum_v dv xi_2, <r, P d>, -
 constexpr int kHistStride = 4;     // xi, xi1, xi2, backtrack
 
 enum KFlags : unsigned {
@@ -82,6 +82,8 @@ struct KArgs {
     const double *z_in, *v_in;  // input iterate; instance b starts at z_in + b*stride_z, v_in + b*stride_v
     double *z_out, *v_out;      // zbar, vbar (same strides)
     double *z_next;             // SUB_BA only: where phase A of the NEXT iteration puts its part of the next zbar (third z buffer)
+    const double *dir;          // SP, sp_mode 2: the direction d (z | v concatenated per instance like z_in), for <r, P d>
+    int sp_mode;                // SP: 0 none, 1 accumulate <r, P r>, 2 also <r, P d>  (spock_device.hpp: b_local SPM)
     double *v2x;                // SUB_BA only: [batch][nsub] vbar.v2 of the subtree roots as recomputed by the crown's workgroup
     long stride_z, stride_v;    // CP: nz, nv (separate arrays); SP: nz + nv for both (z|v concatenated per instance)
     double *dbuf;               // [batch][nn*nu]      S1's d_i between phase A and phase B
@@ -132,12 +134,19 @@ struct SpArgs {
     long nr;
     int op;
     int team;                  // lanes per node of the lane-team LOP (large nx), else 0
+    // fused inner products: <r, P r>, <rt, P rt>, <rt, P d> come out of the CP kernels' phase B (KArgs::sp_mode) as
+    // per-workgroup partial sums in partG[instance][n_partG][kPartialStride] (slots 4, 5, 6) instead of out of LOP kernels
+    const double *partG;
+    int n_partG, fused_lop;
 };
 
 enum SpOp { SP_FLAT1 = 1, SP_FLAT2, SP_FLAT3, SP_FLAT4, SP_FLAT5, SP_LOP_R, SP_LOP_RT, SP_LOP_DP,
             SP_CTL_A, SP_CTL_B, SP_CTL_C, SP_CTL_D };
 
-enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, MODE_FINALIZE = 4, MODE_SUB_BA = 5 };
+// MODE_SUB_B_SP / MODE_FULL_SP: SUB_B / FULL whose phase B also accumulates the SP driver's inner products (KArgs::sp_mode);
+// separate kernels so that the CP kernels do not carry that code and its registers
+enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, MODE_FINALIZE = 4, MODE_SUB_BA = 5,
+                 MODE_SUB_B_SP = 6, MODE_FULL_SP = 7, N_GROUP_MODES = 8 };
 
 // ---- host build step (spock_host.cpp) -------------------------------------------------------------
 struct HostProblem {

@@ -49,6 +49,28 @@ struct GpuExec {
         __syncthreads();
     }
     __device__ __forceinline__ double red3(int k) const { return __longlong_as_double((long long)red[k]); }
+    // deterministic sums over the workgroup (SP inner products): fixed shuffle tree per wave, then the waves in order
+    double sm[3];
+    double *sums;   // LDS [3][8 waves] + [3] results
+    __device__ __forceinline__ void stash_sum3(int, const double *v) { sm[0] = v[0]; sm[1] = v[1]; sm[2] = v[2]; }
+    __device__ __forceinline__ void reduce_sum3() {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double v = sm[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) sums[k * 8 + wave] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double v = sums[threadIdx.x * 8];
+            for (int w = 1; w < nw; ++w) v += sums[threadIdx.x * 8 + w];
+            sums[24 + threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ double sum3(int k) const { return sums[24 + k]; }
 };
 
 #ifdef SPOCK_WAVES_PER_EU   // experiment builds only
@@ -65,7 +87,8 @@ __global__ void __launch_bounds__(512) SPK_KERNEL_ATTR spock_group_kernel(const 
     x.red = reinterpret_cast<unsigned long long *>(smem + a.ex_doubles);
     x.fl = reinterpret_cast<int *>(x.red + 3);
     x.stamps = reinterpret_cast<unsigned long long *>(smem + a.ex_doubles + 4);
-    x.lm = smem + a.ex_doubles + 4 + 128;
+    x.sums = smem + a.ex_doubles + 4 + 128;
+    x.lm = smem + a.ex_doubles + 4 + 128 + 32;
     const bool wave_stamps = (a.flags & F_DBG_STAMPS) && a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && MODE != MODE_FINALIZE;
     unsigned long long *wd = a.dbg ? a.dbg + (long)(MODE == MODE_SUB_A ? 0 : (MODE == MODE_CROWN ? 1 : 2)) * 128 : nullptr;
     if (wave_stamps) wd[2 * (40 + (threadIdx.x >> 6)) + 1] = __builtin_amdgcn_s_memrealtime();
@@ -89,13 +112,15 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     const size_t lds = g.lds_bytes;   // sized for the staged matrices either way
     const dim3 grid(g.grid_x, a.batch), block(g.threads);
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: raise it once per kernel (160 KiB per CU on MI355X)
-        static bool raised[6] = {false, false, false, false, false, false};
+        static bool raised[N_GROUP_MODES] = {false, false, false, false, false, false, false, false};
         if (!raised[mode]) {
             const void *fn = mode == MODE_FULL ? (const void *)spock_group_kernel<P, MODE_FULL>
                            : mode == MODE_SUB_A ? (const void *)spock_group_kernel<P, MODE_SUB_A>
                            : mode == MODE_CROWN ? (const void *)spock_group_kernel<P, MODE_CROWN>
                            : mode == MODE_SUB_B ? (const void *)spock_group_kernel<P, MODE_SUB_B>
                            : mode == MODE_SUB_BA ? (const void *)spock_group_kernel<P, MODE_SUB_BA>
+                           : mode == MODE_SUB_B_SP ? (const void *)spock_group_kernel<P, P::TEAMLOCAL ? MODE_SUB_B : MODE_SUB_B_SP>
+                           : mode == MODE_FULL_SP ? (const void *)spock_group_kernel<P, P::TEAMLOCAL ? MODE_FULL : MODE_FULL_SP>
                                                 : (const void *)spock_group_kernel<P, MODE_FINALIZE>;
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
@@ -110,6 +135,14 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
         case MODE_FINALIZE: hipLaunchKernelGGL((spock_group_kernel<P, MODE_FINALIZE>), grid, block, lds, st, a); break;
         case MODE_SUB_BA:
             hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_BA>), grid, block, lds, st, a);
+            break;
+        case MODE_SUB_B_SP:
+            if constexpr (P::TEAMLOCAL) return (int)hipErrorInvalidConfiguration;   // lane-team handles keep the LOP kernels
+            else hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_B_SP>), grid, block, lds, st, a);
+            break;
+        case MODE_FULL_SP:
+            if constexpr (P::TEAMLOCAL) return (int)hipErrorInvalidConfiguration;
+            else hipLaunchKernelGGL((spock_group_kernel<P, MODE_FULL_SP>), grid, block, lds, st, a);
             break;
         default: return (int)hipErrorInvalidValue;
     }
@@ -245,7 +278,14 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
     if (a.op == SP_CTL_A || a.op == SP_CTL_B)
         for (int r = threadIdx.x; r < a.n_partF; r += kCtlThreads)
             for (int k = 0; k < 6; ++k) f[k] += pf[(long)r * kSpSums + k];
-    if (a.op == SP_CTL_A || a.op == SP_CTL_C)
+    if ((a.op == SP_CTL_A || a.op == SP_CTL_C) && a.fused_lop) {
+        const double *pg = a.partG + (long)inst * a.n_partG * kPartialStride;
+        const double gam = ctl.gamma, sig = ctl.sigma;
+        for (int r = threadIdx.x; r < a.n_partG; r += kCtlThreads) {   // <r, P r> = -gamma sum_z dz xi_1 - sigma sum_v dv xi_2
+            l[0] += -gam * pg[(long)r * kPartialStride + 4] - sig * pg[(long)r * kPartialStride + 5];
+            l[1] += pg[(long)r * kPartialStride + 6];
+        }
+    } else if (a.op == SP_CTL_A || a.op == SP_CTL_C)
         for (int r = threadIdx.x; r < a.n_partL; r += kCtlThreads) { l[0] += pl[(long)r * kSpSums]; l[1] += pl[(long)r * kSpSums + 1]; }
     if (a.op == SP_CTL_D)
         for (int r = threadIdx.x; r < a.n_partL; r += kCtlThreads) {

@@ -72,7 +72,7 @@ SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, dou
         case SP_FLAT5: {
             double z = a.Z[o];
             if (c.accept == 1) z = a.W[o];                           // K1 (sp.jl:166-191)
-            else if (c.accept == 2) z -= c.coef * a.RW[o];           // K2 (sp.jl:193-222)
+            else if (c.accept == 2) z -= c.coef * (a.fused_lop ? a.W[o] - a.WB[o] : a.RW[o]);   // K2 (sp.jl:193-222); rt = w - wbar (:155-160)
             else z = a.ZB[o];                                        // plain CP step (sp.jl:443-446)
             a.Z[o] = z;
             a.DP[o] = z - a.ZOLD[o];                                 // delta_z / delta_v (sp.jl:279-284)

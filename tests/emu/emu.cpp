@@ -51,6 +51,14 @@ struct EmuExec {
         for (int t = 0; t < nthreads_v; ++t) for (int k = 0; k < 3; ++k) r3[k] = spk_max_nan(r3[k], m[t][k]);
     }
     double red3(int k) const { return r3[k]; }
+    std::vector<std::array<double, 3>> sm3;
+    double s3[3] = {0., 0., 0.};
+    void stash_sum3(int tid, const double *v) { if (sm3.size() != m.size()) sm3.assign(m.size(), {0., 0., 0.}); sm3[tid] = {v[0], v[1], v[2]}; }
+    void reduce_sum3() {
+        for (int k = 0; k < 3; ++k) s3[k] = 0.;
+        for (size_t t = 0; t < sm3.size(); ++t) for (int k = 0; k < 3; ++k) s3[k] += sm3[t][k];
+    }
+    double sum3(int k) const { return s3[k]; }
 };
 
 static inline int round64(int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; }
@@ -83,6 +91,8 @@ static int launch_variant(int mode, const KArgs &a_in) {
         case MODE_SUB_B: run_blocks<P, MODE_SUB_B>(a, gx, thr); break;
         case MODE_FINALIZE: run_blocks<P, MODE_FINALIZE>(a, gx, thr); break;
         case MODE_SUB_BA: run_blocks<P, MODE_SUB_BA>(a, gx, thr); break;
+        case MODE_SUB_B_SP: if constexpr (P::TEAMLOCAL) return 9; else run_blocks<P, MODE_SUB_B_SP>(a, gx, thr); break;
+        case MODE_FULL_SP: if constexpr (P::TEAMLOCAL) return 9; else run_blocks<P, MODE_FULL_SP>(a, gx, thr); break;
         default: return 1;
     }
     return 0;
@@ -189,6 +199,14 @@ int launch_sp(const SpArgs &a, void *) {
             for (int r = 0; r < a.n_partL; ++r) {
                 l[0] += pl[(long)r * kSpSums]; l[1] += pl[(long)r * kSpSums + 1];
                 m[0] = spk_max_nan(m[0], pl[(long)r * kSpSums + 2]); m[1] = spk_max_nan(m[1], pl[(long)r * kSpSums + 3]);
+            }
+            if ((a.op == SP_CTL_A || a.op == SP_CTL_C) && a.fused_lop) {
+                const double *pg = a.partG + (long)inst * a.n_partG * kPartialStride;
+                l[0] = l[1] = 0.;
+                for (int r = 0; r < a.n_partG; ++r) {
+                    l[0] += -ctl.gamma * pg[(long)r * kPartialStride + 4] - ctl.sigma * pg[(long)r * kPartialStride + 5];
+                    l[1] += pg[(long)r * kPartialStride + 6];
+                }
             }
             if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0]);
             else if (a.op == SP_CTL_B) sp_ctl_b(c, f);

@@ -167,9 +167,13 @@ def _sp_compare(S, O, m, flat, x0, tol, vb, n_tight=30):
     return r, ro, o
 
 
-@pytest.mark.parametrize("name,tol", [("car", 1e-3), ("sh7", 1e-3), ("sh7_split3", 1e-3), ("d3_static", 1e-3)])
-def test_emulated_sp_driver(S, O, emu, name, tol):
-    """SuperMann + Anderson on the kernel code path (emulated) against the oracle's bug-compatible run_sp!."""
+@pytest.mark.parametrize("name,tol,lop", [("car", 1e-3, False), ("sh7", 1e-3, False), ("sh7_split3", 1e-3, False), ("d3_static", 1e-3, False),
+                                          ("sh7_split3", 1e-3, True), ("car", 1e-3, True)])
+def test_emulated_sp_driver(S, O, emu, name, tol, lop, monkeypatch):
+    """SuperMann + Anderson on the kernel code path (emulated) against the oracle's bug-compatible run_sp!.  Both ways of
+    forming <r, P r>, <rt, P rt>, <rt, P d>: inside phase B of the two T evaluations (default) and with LOP kernels."""
+    if lop:
+        monkeypatch.setenv("SPOCK_AMD_SP_LOP", "1")
     specs = S.get_car_fixture(3.7) if name == "car" else _specs(S, name)     # main_profiling.jl:20-28 scales the costs for SP
     flat = S.flatten_problem(*specs)
     kw = dict(CASES[name][1])
