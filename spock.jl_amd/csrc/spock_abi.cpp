@@ -242,11 +242,11 @@ int launch_sp_T(spock_handle_s *h, double *in, double *out, int sp_mode = 0, con
 
 int launch_sp_iteration(spock_handle_s *h) {
     int e = launch_sp_T(h, h->s_vec[SV_Z], h->s_vec[SV_ZB], 1);
-    if (h->sp_fused) {   // <r, P r>, <rt, P rt>, <rt, P d> come out of phase B of the two T evaluations: 15 launches
+    if (h->sp_fused) {   // every inner product and residual norm comes out of phase B of the two T evaluations: 13 launches
         const int seq1[] = {SP_FLAT1, SP_CTL_A, SP_FLAT2, SP_CTL_B, SP_FLAT3};
         for (int op : seq1) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
         if (!e) e = launch_sp_T(h, h->s_vec[SV_W], h->s_vec[SV_WB], 2, h->s_vec[SV_D]);
-        const int seq2[] = {SP_CTL_C, SP_FLAT5, SP_LOP_DP, SP_CTL_D};
+        const int seq2[] = {SP_CTL_CD, SP_FLAT5};
         for (int op : seq2) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
         return e;
     }

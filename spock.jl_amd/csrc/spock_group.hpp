@@ -22,6 +22,7 @@
 #pragma once
 #include "spock_device.hpp"
 #include "spock_team_local.hpp"
+#include "spock_sp.hpp"
 #ifdef SPOCK_HOST_EMU
 #include <cstdlib>
 #endif
@@ -459,6 +460,19 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         if (SP_SUMS && !team_local) {
             x.reduce_sum3();
             x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + 4 + tid] = x.sum3(tid); });
+            if (a.sp_mode == 2) {   // the termination residuals of the direction d itself (K1 step: dp = d), spock_sp.hpp: sp_ctl_cd
+                const double *dd_ = a.dir + (long)inst * a.stride_z;
+                x.each([&](int tid, TState<P> &s) {
+                    double acc[4] = {0., 0., 0., 0.};
+                    if (s.active) lop_local(p, dm, M, nullptr, dd_, nullptr, s, gamma, sigma, acc);
+                    const double mx[3] = {acc[2], acc[3], 0.};
+                    x.stash3(tid, mx);
+                });
+                x.reduce3();
+                x.each([&](int tid, TState<P> &) {
+                    if (tid == 0) { partials[(long)slot * kPartialStride + 3] = x.red3(0); partials[(long)slot * kPartialStride + 7] = x.red3(1); }
+                });
+            }
         }
         stamp();   // phase B done
     };

@@ -59,7 +59,8 @@ struct Ctl {
     double gamma, sigma, tol;
 };
 
-constexpr int kPartialStride = 8;  // per workgroup: xi1, xi2, xi, - | SP: sum_z dz xi_1, sum_v dv xi_2, <r, P d>, -
+// per workgroup: xi1, xi2, xi, |L'd_v - d_z/gamma| | SP: sum_z dz xi_1, sum_v dv xi_2, <r, P d>, |L d_z - d_v/sigma|
+constexpr int kPartialStride = 8;
 constexpr int kHistStride = 4;     // xi, xi1, xi2, backtrack
 
 enum KFlags : unsigned {
@@ -113,6 +114,7 @@ struct SpCtl {          // per instance, device memory; survives between solves 
     double R[9];        // aa_R, column-major 3x3 upper triangular; persists between solves
     double r_safe, rnorm, rtilde, rho_dot, coef;
     double r2, r3, rho, g[3];
+    double xi_fb[2];    // residuals of the plain CP step z <- T(z) (the fall-back), kept from the first T evaluation
 };
 
 constexpr int kSpSums = 10;   // partial sums per workgroup of the flat / LOP kernels
@@ -141,7 +143,7 @@ struct SpArgs {
 };
 
 enum SpOp { SP_FLAT1 = 1, SP_FLAT2, SP_FLAT3, SP_FLAT4, SP_FLAT5, SP_LOP_R, SP_LOP_RT, SP_LOP_DP,
-            SP_CTL_A, SP_CTL_B, SP_CTL_C, SP_CTL_D };
+            SP_CTL_A, SP_CTL_B, SP_CTL_C, SP_CTL_D, SP_CTL_CD };
 
 // MODE_SUB_B_SP / MODE_FULL_SP: SUB_B / FULL whose phase B also accumulates the SP driver's inner products (KArgs::sp_mode);
 // separate kernels so that the CP kernels do not carry that code and its registers

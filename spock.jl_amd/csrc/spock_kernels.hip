@@ -216,7 +216,8 @@ __device__ __forceinline__ void block_reduce(double *v, double *lds /* [K][16] *
 
 __global__ void __launch_bounds__(kFlatThreads) spock_sp_flat_kernel(const SpArgs a) {
     const int inst = blockIdx.y;
-    if (a.ctl[inst].done) return;
+    const int done = a.ctl[inst].done;
+    if (done == 1 || (done && a.op != SP_FLAT5)) return;   // done == 2: the state update of the final iteration still runs
     __shared__ double red[6 * 16];
     const SpCtl c = a.sp[inst];
     double sums[6] = {0., 0., 0., 0., 0., 0.};
@@ -270,7 +271,10 @@ __global__ void __launch_bounds__(512) spock_sp_lop_kernel(const SpArgs a) {
 __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs a) {
     const int inst = blockIdx.y;
     Ctl &ctl = a.ctl[inst];
-    if (ctl.done) return;
+    if (ctl.done) {
+        if (a.op == SP_CTL_A && ctl.done == 2 && threadIdx.x == 0) ctl.done = 1;   // the final state update has run
+        return;
+    }
     __shared__ double red[6 * 16];
     SpCtl &c = a.sp[inst];
     const double *pf = a.partF + (long)inst * a.n_partF * kSpSums, *pl = a.partL + (long)inst * a.n_partL * kSpSums;
@@ -278,12 +282,15 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
     if (a.op == SP_CTL_A || a.op == SP_CTL_B)
         for (int r = threadIdx.x; r < a.n_partF; r += kCtlThreads)
             for (int k = 0; k < 6; ++k) f[k] += pf[(long)r * kSpSums + k];
-    if ((a.op == SP_CTL_A || a.op == SP_CTL_C) && a.fused_lop) {
+    double g2[2] = {0., 0.};
+    if ((a.op == SP_CTL_A || a.op == SP_CTL_C || a.op == SP_CTL_CD) && a.fused_lop) {
         const double *pg = a.partG + (long)inst * a.n_partG * kPartialStride;
         const double gam = ctl.gamma, sig = ctl.sigma;
         for (int r = threadIdx.x; r < a.n_partG; r += kCtlThreads) {   // <r, P r> = -gamma sum_z dz xi_1 - sigma sum_v dv xi_2
             l[0] += -gam * pg[(long)r * kPartialStride + 4] - sig * pg[(long)r * kPartialStride + 5];
             l[1] += pg[(long)r * kPartialStride + 6];
+            m[0] = spk_max_nan(m[0], pg[(long)r * kPartialStride + 0]); m[1] = spk_max_nan(m[1], pg[(long)r * kPartialStride + 1]);
+            g2[0] = spk_max_nan(g2[0], pg[(long)r * kPartialStride + 3]); g2[1] = spk_max_nan(g2[1], pg[(long)r * kPartialStride + 7]);
         }
     } else if (a.op == SP_CTL_A || a.op == SP_CTL_C)
         for (int r = threadIdx.x; r < a.n_partL; r += kCtlThreads) { l[0] += pl[(long)r * kSpSums]; l[1] += pl[(long)r * kSpSums + 1]; }
@@ -296,8 +303,12 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
     block_reduce<2, false>(l, red);
     __syncthreads();
     block_reduce<2, true>(m, red);
+    __syncthreads();
+    block_reduce<2, true>(g2, red);
     if (threadIdx.x == 0) {
-        if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0]);
+        double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
+        if (a.op == SP_CTL_CD) sp_ctl_cd(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], hist, a.hist_cap);
+        else if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0], m[0], m[1]);
         else if (a.op == SP_CTL_B) sp_ctl_b(c, f);
         else if (a.op == SP_CTL_C) sp_ctl_c(c, ctl, l[0], l[1]);
         else if (a.op == SP_CTL_D) sp_ctl_d(c, ctl, m[0], m[1], a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr, a.hist_cap);
@@ -344,7 +355,7 @@ int launch_sp(const SpArgs &a, void *stream) {
         case SP_FLAT1: case SP_FLAT2: case SP_FLAT3: case SP_FLAT4: case SP_FLAT5:
             hipLaunchKernelGGL(spock_sp_flat_kernel, dim3(a.n_partF, a.batch), dim3(kFlatThreads), 0, st, a);
             return (int)hipGetLastError();
-        case SP_CTL_A: case SP_CTL_B: case SP_CTL_C: case SP_CTL_D:
+        case SP_CTL_A: case SP_CTL_B: case SP_CTL_C: case SP_CTL_D: case SP_CTL_CD:
             hipLaunchKernelGGL(spock_sp_ctl_kernel, dim3(1, a.batch), dim3(kCtlThreads), 0, st, a);
             return (int)hipGetLastError();
         default: break;

@@ -193,7 +193,8 @@ SPK_DEV void lop_local(const P &p, const Dims &dm, MatPtr M, const double *__res
 
 // ---------------------------------------------------------------------------------------------------
 // control steps, ONE thread per instance; `sums` are the reduced partial sums of the preceding kernel(s)
-SPK_DEV void sp_ctl_a(SpCtl &c, const double *gram, double pr) {
+SPK_DEV void sp_ctl_a(SpCtl &c, const double *gram, double pr, double xi1 = 0., double xi2 = 0.) {
+    c.xi_fb[0] = xi1; c.xi_fb[1] = xi2;
     c.rnorm = sqrt(pr);                                              // sp.jl:395, implicit_l.jl:545-557
     c.k += 1;                                                        // generate_qnewton_direction! (models/spock.jl:212-224)
     // shift R diagonally (anderson.jl:46-50); reads below the diagonal of the UpperTriangular give 0
@@ -231,7 +232,10 @@ SPK_DEV void sp_ctl_c(SpCtl &c, const Ctl &ctl, double s_rt, double s_rtd) {
         c.coef = lambda_sp * (rho / (c.rtilde * c.rtilde));          // sp.jl:211-218
     }
 }
-SPK_DEV void sp_ctl_d(SpCtl &c, Ctl &ctl, double x1, double x2, double *hist, int hist_cap) {
+// `fin`: the value `done` takes when the solve ends here.  The merged control step CTL_CD runs BEFORE the state update
+// FLAT5 of its iteration, so it ends a solve with done = 2 ("finishing": FLAT5 still applies the accepted step, every
+// other kernel already exits); the next CTL_A turns 2 into 1.  The host treats any non-zero value as finished.
+SPK_DEV void sp_ctl_d(SpCtl &c, Ctl &ctl, double x1, double x2, double *hist, int hist_cap, int fin = 1) {
     c.head = (c.head + 2) % 3;     // the next anderson! call writes its new column into the slot of the oldest one
     const bool log = (ctl.log_mode == 2);
     const double xi = log ? (x1 > x2 ? x1 : x2) : NAN;               // sp.jl:308
@@ -250,10 +254,26 @@ SPK_DEV void sp_ctl_d(SpCtl &c, Ctl &ctl, double x1, double x2, double *hist, in
     }
     if (ctl.res0[0] == -INFINITY) ctl.res0[0] = x1;
     if (ctl.res0[1] == -INFINITY) ctl.res0[1] = x2;
-    if (x1 != x1 || x2 != x2) { ctl.done = 1; ctl.status = 2; return; }   // the reference would spin to MAX_ITER on NaNs
-    if (term) { ctl.done = 1; ctl.status = 0; return; }
+    if (x1 != x1 || x2 != x2) { ctl.done = fin; ctl.status = 2; return; }   // the reference would spin to MAX_ITER on NaNs
+    if (term) { ctl.done = fin; ctl.status = 0; return; }
     ctl.iter += 1;
-    if (ctl.iter >= ctl.max_iter) { ctl.done = 1; ctl.status = 1; return; }
+    if (ctl.iter >= ctl.max_iter) { ctl.done = fin; ctl.status = 1; return; }
+}
+
+// CTL_C and CTL_D in one step (fused sequence).  The termination residuals xi_1 = |L' dp_v - dp_z / gamma|_inf,
+// xi_2 = |L dp_z - dp_v / sigma|_inf of dp = z_new - z_old (sp.jl:283-293) need no pass of their own: by linearity
+//   K1: dp = w - z = d          -> the residuals of d, formed next to phase B of T(w)      (ld1, ld2)
+//   K2: dp = -coef rt           -> coef times the CP residuals of the evaluation T(w)      (xw1, xw2)
+//   CP: dp = zbar - z           -> the CP residuals of the evaluation T(z)                 (c.xi_fb)
+// (dp differs from these by the rounding of z_new - z_old, relative size eps |z| / |dp|.)
+SPK_DEV void sp_ctl_cd(SpCtl &c, Ctl &ctl, double s_rt, double s_rtd, double xw1, double xw2, double ld1, double ld2,
+                       double *hist, int hist_cap) {
+    sp_ctl_c(c, ctl, s_rt, s_rtd);
+    double x1, x2;
+    if (c.accept == 1) { x1 = ld1; x2 = ld2; }
+    else if (c.accept == 2) { const double f = fabs(c.coef); x1 = f * xw1; x2 = f * xw2; }
+    else { x1 = c.xi_fb[0]; x2 = c.xi_fb[1]; }
+    sp_ctl_d(c, ctl, x1, x2, hist, hist_cap, 2);
 }
 
 }  // namespace spock

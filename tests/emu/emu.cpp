@@ -177,7 +177,8 @@ int launch_sp(const SpArgs &a, void *) {
     const Dims &dm = a.dm;
     if (a.op >= SP_FLAT1 && a.op <= SP_FLAT5) {
         for (int inst = 0; inst < a.batch; ++inst) {
-            if (a.ctl[inst].done) continue;
+            const int done = a.ctl[inst].done;
+            if (done == 1 || (done && a.op != SP_FLAT5)) continue;   // done == 2: the state update of the final iteration still runs
             const SpCtl c = a.sp[inst];
             for (int blk = 0; blk < a.n_partF; ++blk) {
                 double sums[6] = {0., 0., 0., 0., 0., 0.};
@@ -191,7 +192,7 @@ int launch_sp(const SpArgs &a, void *) {
     if (a.op >= SP_CTL_A) {
         for (int inst = 0; inst < a.batch; ++inst) {
             Ctl &ctl = a.ctl[inst];
-            if (ctl.done) continue;
+            if (ctl.done) { if (a.op == SP_CTL_A && ctl.done == 2) ctl.done = 1; continue; }
             SpCtl &c = a.sp[inst];
             const double *pf = a.partF + (long)inst * a.n_partF * kSpSums, *pl = a.partL + (long)inst * a.n_partL * kSpSums;
             double f[6] = {0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
@@ -200,15 +201,20 @@ int launch_sp(const SpArgs &a, void *) {
                 l[0] += pl[(long)r * kSpSums]; l[1] += pl[(long)r * kSpSums + 1];
                 m[0] = spk_max_nan(m[0], pl[(long)r * kSpSums + 2]); m[1] = spk_max_nan(m[1], pl[(long)r * kSpSums + 3]);
             }
-            if ((a.op == SP_CTL_A || a.op == SP_CTL_C) && a.fused_lop) {
+            double g2[2] = {0., 0.};
+            if ((a.op == SP_CTL_A || a.op == SP_CTL_C || a.op == SP_CTL_CD) && a.fused_lop) {
                 const double *pg = a.partG + (long)inst * a.n_partG * kPartialStride;
-                l[0] = l[1] = 0.;
+                l[0] = l[1] = 0.; m[0] = m[1] = 0.;
                 for (int r = 0; r < a.n_partG; ++r) {
                     l[0] += -ctl.gamma * pg[(long)r * kPartialStride + 4] - ctl.sigma * pg[(long)r * kPartialStride + 5];
                     l[1] += pg[(long)r * kPartialStride + 6];
+                    m[0] = spk_max_nan(m[0], pg[(long)r * kPartialStride + 0]); m[1] = spk_max_nan(m[1], pg[(long)r * kPartialStride + 1]);
+                    g2[0] = spk_max_nan(g2[0], pg[(long)r * kPartialStride + 3]); g2[1] = spk_max_nan(g2[1], pg[(long)r * kPartialStride + 7]);
                 }
             }
-            if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0]);
+            double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
+            if (a.op == SP_CTL_CD) sp_ctl_cd(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], hist, a.hist_cap);
+            else if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0], m[0], m[1]);
             else if (a.op == SP_CTL_B) sp_ctl_b(c, f);
             else if (a.op == SP_CTL_C) sp_ctl_c(c, ctl, l[0], l[1]);
             else sp_ctl_d(c, ctl, m[0], m[1], a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr, a.hist_cap);
