@@ -405,7 +405,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     if (const char *e = std::getenv("SPOCK_AMD_SPLIT_STAGE")) split = std::atoi(e);
 
     bool unsupported = false;
-    const std::string msg = host_build(hp, split, h->bp, unsupported);
+    const std::string msg = host_build(hp, split, h->bp, unsupported, h->batch);
     if (!msg.empty()) { delete h; return fail(unsupported ? SPOCK_ERR_UNSUPPORTED : SPOCK_ERR_BUILD, msg); }
     if (o && o->L_norm < 0.) h->L_norm = h->bp.L_norm_closed * (1. + 1e-9);   // negative: closed form instead of the hard-coded constant
     const Dims &dm = h->bp.dm;

@@ -128,7 +128,7 @@ int group_threads(int d, int stages) { return stages < 2 ? 0 : (ipow(d, stages -
 
 // Stage at which the tree is cut.  A group (subtree or crown) runs as ONE workgroup with one thread per
 // non-leaf node and nx doubles of LDS per thread for the q / x exchange of the S1 sweeps.
-int choose_split_stage(int N, int d, int nx) {
+int choose_split_stage(int N, int d, int nx, int nu, int batch) {
     int max_thr = 512;
     const int lds_thr = (144 * 1024 / 8) / (nx > 0 ? nx : 1);
     if (lds_thr < max_thr) max_thr = lds_thr;
@@ -138,6 +138,11 @@ int choose_split_stage(int N, int d, int nx) {
     int t0 = (N - 1) / 2;
     while (t0 < N - 2 && group_threads(d, N - t0) > max_thr) ++t0;
     if (group_threads(d, N - t0) > max_thr || group_threads(d, t0 + 1) > max_thr) return -1;
+    // Batched regime (thousands of workgroups in flight, one thread per node): subtrees of two waves instead of one are
+    // ~7 % faster (measured: N = 13, d = 2, 256 instances, 490 k -> 527 k iterations/s at t0 = 5; t0 = 4 the same, t0 = 3 slower;
+    // for a single instance t0 = 6 stays best: 42.7 vs 46 us per iteration)
+    if (nx <= 8 && nu <= 8 && (long)batch * ipow(d, t0) >= 1024)
+        while (t0 > 1 && group_threads(d, N - (t0 - 1)) <= 128) --t0;
     return t0;
 }
 
@@ -218,7 +223,7 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     return g;
 }
 
-std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported) {
+std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported, int batch) {
     unsupported = false;
     const int N = hp.N, d = hp.d, nx = hp.nx, nu = hp.nu, ny = hp.ny;
     if (d <= 1) return "Branching factor d must be larger than 1";       // scenario_tree.jl:62-64
@@ -267,7 +272,7 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
     dm.x_min = hp.x_min; dm.x_max = hp.x_max; dm.u_min = hp.u_min; dm.u_max = hp.u_max;
     for (int t = 0; t <= N; ++t) dm.first[t] = (ipow(d, t) - 1) / (d - 1);
 
-    int t0 = split_stage > 0 ? split_stage : choose_split_stage(N, d, nx);
+    int t0 = split_stage > 0 ? split_stage : choose_split_stage(N, d, nx, nu, batch);
     if (t0 < 0) { unsupported = true; return "tree does not fit the two-level subtree tiling"; }
     if (t0 > 0) {
         if (t0 > N - 2) return "split_stage must leave subtrees of at least two stages";

@@ -166,8 +166,8 @@ struct BuildProducts {
     double L_norm_closed = 0.;   // ||L||^2 in closed form; the reference hard-codes 10.0 / 3.28
 };
 // returns "" on success, else an error message; split_stage 0 = choose
-std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported);
-int choose_split_stage(int N, int d, int nx);
+std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported, int batch = 1);
+int choose_split_stage(int N, int d, int nx, int nu = 0, int batch = 1);
 // launch geometry shared by the GPU launcher and the emulation harness
 struct LaunchGeo { int threads, grid_x, team, team_reg, team_local, lds_mats, ex_doubles; size_t lds_bytes; };
 bool team_local_applies(const Dims &dm);   // lane-team node-local phases: large nx / nu, shared diagonal costs, no SOC risk cone
