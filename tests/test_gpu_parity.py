@@ -338,3 +338,61 @@ def test_full_size_cfg2_properties(S):
         assert np.allclose(x[0], x0)
         assert r["iterations"] >= 1
         m.close()
+
+
+@pytest.mark.parametrize("N,nu,batch", [(10, 5, 1), (10, 2, 1), (11, 5, 24)])
+def test_fused_and_three_kernel_sequences_agree(S, O, monkeypatch, N, nu, batch):
+    """CP iteration as CROWN + SUB_BA (phase B of iteration k fused with phase A of k + 1, three z buffers) against the
+    plain SUB_A + CROWN + SUB_B sequence and the oracle: same iteration counts, iterates to rounding.  The batch case runs
+    in the one-thread-per-node regime and lets the instances finish at different iterations."""
+    specs = S.get_server_heat_specs(N, 5, 2, nu=nu)
+    flat = S.flatten_problem(*specs)
+    x0 = np.full((batch, 5), 0.1) * (1 + 0.05 * np.arange(batch))[:, None]
+    tol, mi = (1e-3, 5000) if nu == 5 else (0.0, 150)      # nu = 2 < nx is infeasible: fixed work instead of a tolerance
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SPOCK_AMD_FUSE", fuse)
+        m = S.build_model(*specs, batch=batch, max_iter=mi)
+        assert int(m.sizes.fused_iteration) == int(fuse)
+        r = S.solve_model(m, x0 if batch > 1 else x0[0], tol=tol)
+        rs = r if isinstance(r, list) else [r]
+        out[fuse] = ([q["iterations"] for q in rs], np.array(m.solver_state.z, copy=True).reshape(batch, -1),
+                     np.array(m.solver_state.v, copy=True).reshape(batch, -1))
+        # a second, warm-started solve must continue from the state the first one left (buffer rotation back to slot 0)
+        r2 = S.solve_model(m, x0 if batch > 1 else x0[0], tol=tol)
+        out[fuse + "w"] = [q["iterations"] for q in (r2 if isinstance(r2, list) else [r2])]
+        m.close()
+    assert out["1"][0] == out["0"][0] and out["1w"] == out["0w"]
+    assert relerr(out["1"][1], out["0"][1]) <= 1e-11 and relerr(out["1"][2], out["0"][2]) <= 1e-11
+    o = O.Oracle(flat, O.CP)
+    ro = o.solve(x0[0], tol=tol, max_iter=mi)
+    assert ro["iterations"] == out["1"][0][0] and relerr(out["1"][1][0], o.z) <= 1e-8
+
+
+def test_sp_batch_matches_single_and_lop_sequence(S, O, monkeypatch):
+    """SP with the inner products accumulated inside phase B (13 launches per iteration, merged control step, done = 2
+    hand-over to the last state update): a batch whose instances stop at different iterations equals the same instances
+    solved one at a time, and the first iterations agree with the LOP-kernel sequence and with the oracle."""
+    specs = S.get_server_heat_specs(10, 5, 2)
+    flat = S.flatten_problem(*specs)
+    x0 = np.full((3, 5), 0.1) * np.array([1.0, 1.3, 0.7])[:, None]
+    mb = S.build_model(*specs, S.SolverOptions(S.SP, None), batch=3)
+    rb = S.solve_model(mb, x0, tol=1e-3)
+    zb = np.array(mb.solver_state.z, copy=True); hb = [mb.history(k) for k in range(3)]
+    mb.close()
+    its = [q["iterations"] for q in rb]
+    assert all(q["status"] == 0 for q in rb) and len(set(its)) > 1
+    for k in range(3):
+        m1 = S.build_model(*specs, S.SolverOptions(S.SP, None))
+        r1 = S.solve_model(m1, x0[k], tol=1e-3)
+        assert r1["iterations"] == its[k] and relerr(m1.solver_state.z, zb[k]) <= 1e-12
+        m1.close()
+    monkeypatch.setenv("SPOCK_AMD_SP_LOP", "1")
+    ml = S.build_model(*specs, S.SolverOptions(S.SP, None))
+    S.solve_model(ml, x0[0], tol=1e-3)
+    hl = ml.history(); ml.close()
+    o = O.Oracle(flat, O.SP); ro = o.solve(x0[0], tol=1e-3, history=2000)
+    n = min(25, len(hl["xi1"]), len(hb[0]["xi1"]), len(ro["hist_xi1"]))
+    assert np.max(np.abs(hb[0]["xi1"][:n] - hl["xi1"][:n]) / hl["xi1"][:n]) <= 1e-8
+    assert np.max(np.abs(hb[0]["xi1"][:n] - ro["hist_xi1"][:n]) / ro["hist_xi1"][:n]) <= 1e-8
+    assert np.array_equal(hb[0]["backtrack"][:n], ro["hist_backtrack"][:n])
