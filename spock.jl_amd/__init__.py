@@ -11,5 +11,6 @@ from .model import (CP, LOG, SILENT, SP, AlgorithmOptions, Model, QNewtonOptions
                     build_model, mpc_simulation, solve_model, solve_model_bang)
 from ._lib import SpockError, load_library
 from .examples import L_norm_sq, get_car_fixture, get_random_linear_specs, get_server_heat_specs
+from .validate import check_solution
 
 __all__ = [n for n in dir() if not n.startswith("_")]
