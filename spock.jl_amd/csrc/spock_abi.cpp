@@ -36,6 +36,7 @@ struct spock_handle_s {
     bool sp_fused = false;   // SP: the inner products with the residuals come out of phase B instead of out of LOP kernels
     bool fused = false;   // CP iteration = CROWN + SUB_BA (after one SUB_A) instead of SUB_A + CROWN + SUB_B
     double *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_partials = nullptr, *d_x0 = nullptr, *d_hist = nullptr;
+    double *d_xlbuf = nullptr;
     Ctl *d_ctl = nullptr;
     unsigned long long *d_dbg = nullptr;
     int hist_cap = 0;
@@ -88,6 +89,7 @@ KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
         a.hist = nullptr; a.hist_cap = 0; a.batch = 1;
     }
     a.stride_z = h->bp.dm.nz; a.stride_v = h->bp.dm.nv;
+    a.xlbuf = h->d_xlbuf;
     a.parity = parity;
     a.flags = flags;
     return a;
@@ -442,6 +444,13 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         (e = dev_alloc(h, &h->d_hist, B * (size_t)h->hist_cap * kHistStride)) || (e = dev_alloc(h, &h->d_ctl, B)) ||
         (e = dev_alloc(h, &h->d_dbg, (size_t)3 * 64 * 2)))
         return bail(e, "hipMalloc(workspace)");
+    {   // group-leaf sweep vector in global memory, when the lane-team vectors do not all fit in LDS
+        const LaunchGeo g1 = launch_geometry(dm.t0 > 0 ? MODE_SUB_A : MODE_FULL, dm, h->batch), g2 = launch_geometry(MODE_CROWN, dm, h->batch);
+        if ((g1.team && g1.xl_global) || (dm.t0 > 0 && g2.team && g2.xl_global)) {
+            const size_t stride = (size_t)(g1.xl_stride > g2.xl_stride ? g1.xl_stride : g2.xl_stride);
+            if ((e = dev_alloc(h, &h->d_xlbuf, B * (size_t)(dm.nsub + 1) * stride))) return bail(e, "hipMalloc(workspace)");
+        }
+    }
     h->h_ctl.assign(B, fresh_ctl(h, 0., 0., 0., SPOCK_SILENT));
     for (auto &c : h->h_ctl) c.done = 1;
     if ((e = rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream))) return bail(e, "upload");

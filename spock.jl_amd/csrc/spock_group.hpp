@@ -140,6 +140,11 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     for (int k = 0; k < stages - 1; ++k) ngl_grp *= p.d();
     TeamLds tl;
     tl.XQ = ex; tl.ED = tl.XQ + nl_grp * p.nx(); tl.UL = tl.ED + nl_grp * p.nu(); tl.XL = tl.UL + nl_grp * p.nu();
+    double *lds_after_vectors = tl.XL + ngl_grp * p.nx();
+    if (a.xl_global) {   // the group-leaf vector in global memory (one slice per workgroup), everything else as before
+        lds_after_vectors = tl.XL;
+        tl.XL = a.xlbuf + ((long)inst * n_groups + g) * a.xl_stride;
+    }
 
     // register-resident variant of the team sweep: rows of this thread's node in registers, loaded before phase A so that
     // their latency hides behind it
@@ -187,7 +192,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // lane-team node-local phases (large nx / nu, diagonal costs): T lanes per node, team scratch behind the sweep vectors
     const bool team_local = P::TEAMLOCAL;
     const int TT = a.team > 0 ? a.team : 8, nteams = nthr / TT;
-    double *tscr = tl.XL + ngl_grp * nx;
+    double *tscr = lds_after_vectors;
     const int tscr_stride = team_scratch_doubles(nu, p.ny() + 2 * d, d, TT);
 
     // ---- phase A (node-local) on the iterate (zi, vi); its part of zbar goes to zout, c_i / e_i (and the leaves' xbar) to

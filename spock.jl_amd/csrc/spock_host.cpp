@@ -166,7 +166,7 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
         default: stage_sets[n_sets++] = 2; g.grid_x = 1; break;
     }
     int nl = 0, widest = 1, max_stages = 2;
-    long team_doubles = 0;
+    long team_doubles = 0, team_doubles_noxl = 0, xl_doubles = 0;
     for (int k = 0; k < n_sets; ++k) {
         const int st = stage_sets[k];
         const int nonleaf = group_threads(d, st), leaves = ipow(d, st - 1);
@@ -175,6 +175,8 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
         if (st >= 2 && ipow(d, st - 2) > widest) widest = ipow(d, st - 2);
         const long td = (long)nonleaf * (nx + 2 * nu) + (long)leaves * nx;
         if (td > team_doubles) team_doubles = td;
+        if ((long)nonleaf * (nx + 2 * nu) > team_doubles_noxl) team_doubles_noxl = (long)nonleaf * (nx + 2 * nu);
+        if ((long)leaves * nx > xl_doubles) xl_doubles = (long)leaves * nx;
     }
     int T = 8;
     while (T < nx || T < nu) T *= 2;
@@ -190,6 +192,12 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     // T x (non-leaf nodes of the group) threads; the crown kernel (one workgroup per instance) always qualifies.
     bool want_team = (nx > 8 || nu > 8);
     const bool small = (nx <= 8 && nu <= 8);
+    g.xl_global = 0; g.xl_stride = (int)xl_doubles;
+    // large nx, deep groups (config 5: nx = 64, 127-node groups = 163 KB): keep c / e / u in LDS and put the group-leaf
+    // vector (half of the footprint, touched only at the bottom level) in global memory rather than fall back to the
+    // one-thread-per-node kernels (34 ms per iteration there)
+    const bool force_xl = std::getenv("SPOCK_AMD_FORCE_XL_GLOBAL") != nullptr;   // tests: exercise the path on small problems
+    if (want_team && (team_doubles * 8 + tail > 144 * 1024 || force_xl) && !std::getenv("SPOCK_AMD_NO_XL_GLOBAL")) { g.xl_global = 1; team_doubles = team_doubles_noxl; }
     const long wgs = (long)batch * g.grid_x;
     bool want_reg = small && (long)T * nl <= 512 && (mode == MODE_CROWN || wgs < 512);
     if (const char *e = std::getenv("SPOCK_AMD_TEAM")) want_team = (e[0] == '1');

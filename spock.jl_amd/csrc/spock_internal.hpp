@@ -103,6 +103,8 @@ struct KArgs {
     int ex_doubles;             // size of the LDS exchange region (thread path: threads*nx; team path: TeamLds vectors)
     int team_reg;               // lane-team sweep with the matrix rows in registers (small compile-time shapes)
     int team;                   // > 0: lane-team sweeps with this many lanes per node (all sweep vectors in LDS)
+    double *xlbuf;              // [batch][groups][xl_stride]: the group-leaf sweep vector when it does not fit in LDS
+    int xl_global, xl_stride;
 };
 
 // ---- SP (SuperMann + Anderson) driver: plain data shared by the kernels (spock_sp.hpp) and the driver ----
@@ -169,7 +171,9 @@ struct BuildProducts {
 std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &out, bool &unsupported, int batch = 1);
 int choose_split_stage(int N, int d, int nx, int nu = 0, int batch = 1);
 // launch geometry shared by the GPU launcher and the emulation harness
-struct LaunchGeo { int threads, grid_x, team, team_reg, team_local, lds_mats, ex_doubles; size_t lds_bytes; };
+// xl_global: the lane-team sweep's vector over the GROUP LEAVES (q in, x out) lives in global memory instead of LDS
+// (xl_stride doubles per workgroup): large nx with deep groups, where all four sweep vectors do not fit 144 KiB
+struct LaunchGeo { int threads, grid_x, team, team_reg, team_local, lds_mats, ex_doubles, xl_global, xl_stride; size_t lds_bytes; };
 bool team_local_applies(const Dims &dm);   // lane-team node-local phases: large nx / nu, shared diagonal costs, no SOC risk cone
 LaunchGeo launch_geometry(int mode, const Dims &dm, int batch);
 int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tree with `stages` stages

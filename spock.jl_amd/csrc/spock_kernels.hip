@@ -108,6 +108,8 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     bool stage = g.lds_mats && ((long)a.batch * g.grid_x >= 1024 || g.team);
     if (const char *e = std::getenv("SPOCK_AMD_LDS_MATS")) stage = g.lds_mats && e[0] == '1';
     a.lds_mats = stage ? 1 : 0; a.team = g.team; a.team_reg = g.team_reg; a.ex_doubles = g.ex_doubles;
+    a.xl_global = (g.team && g.xl_global && a.xlbuf) ? 1 : 0; a.xl_stride = g.xl_stride;
+    if (g.team && g.xl_global && !a.xlbuf) return (int)hipErrorInvalidValue;
     if (P::TEAMLOCAL && !g.team_local && mode != MODE_FINALIZE) return (int)hipErrorInvalidConfiguration;
     const size_t lds = g.lds_bytes;   // sized for the staged matrices either way
     const dim3 grid(g.grid_x, a.batch), block(g.threads);

@@ -82,6 +82,8 @@ static int launch_variant(int mode, const KArgs &a_in) {
     const LaunchGeo g = launch_geometry(mode, a.dm, a.batch);
     a.lds_mats = env_on("SPOCK_EMU_NO_LDS_MATS") ? 0 : g.lds_mats;
     a.team = g.team; a.team_reg = g.team_reg; a.ex_doubles = g.ex_doubles;
+    a.xl_global = (g.team && g.xl_global && a.xlbuf) ? 1 : 0; a.xl_stride = g.xl_stride;
+    if (g.team && g.xl_global && !a.xlbuf) return 9;
     const int thr = g.threads, gx = g.grid_x;
     if (thr > 512) return 9;
     switch (mode) {

@@ -354,6 +354,33 @@ def test_emulated_fused_iteration_is_order_independent(S, O, emu, env, ok, monke
         assert good == ok, (split, env)
 
 
+def test_emulated_group_leaf_vector_in_global_memory(S, O, emu, monkeypatch):
+    """Large nx with deep groups (BASELINE config 5 at N = 15): the lane-team sweep keeps c / e / u in LDS and the vector over
+    the group leaves in global memory.  Forced here on small problems; operators, CP and SP against the oracle."""
+    monkeypatch.setenv("SPOCK_AMD_FORCE_XL_GLOBAL", "1")
+    for specs, kw in ((S.get_random_linear_specs(5, 12, 4), {"split_stage": 2}), (S.get_server_heat_specs(6, 20, 2), {}),
+                      (S.get_server_heat_specs(4, 10, 3, p_ref=[0.2, 0.3, 0.5]), {"split_stage": 1})):
+        flat = S.flatten_problem(*specs)
+        m = S.build_model(*specs, lib_path=emu, L_norm="auto", graph_iters=-6, **kw)
+        o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm
+        rng = np.random.default_rng(4)
+        z = rng.standard_normal(flat.nz); v = rng.standard_normal(flat.nv); x0 = np.full(flat.nx, 0.1)
+        zo, vo = m.T(z, v, 0.3, 0.25, x0); zr, vr = o.T(z, v, 0.3, 0.25, x0)
+        assert relerr(zo, zr) <= 1e-11 and relerr(vo, vr) <= 1e-11
+        assert relerr(m.prox_f(z, 0.1, x0), o.prox_f(z, 0.1, x0)) <= 1e-11
+        r = S.solve_model(m, x0, tol=1e-3); ro = o.solve(x0, tol=1e-3)
+        assert (r["iterations"], r["status"]) == (ro["iterations"], ro["status"]) and relerr(m.solver_state.z, o.z) <= 1e-8
+        m.close()
+    specs = S.get_server_heat_specs(6, 20, 2)
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, graph_iters=-2)
+    o = O.Oracle(flat, O.SP)
+    r = S.solve_model(m, np.full(20, 0.1), tol=1e-3); ro = o.solve(np.full(20, 0.1), tol=1e-3, history=3000)
+    h = m.history(); n = min(20, len(h["xi1"]), len(ro["hist_xi1"]))
+    assert np.max(np.abs(h["xi1"][:n] - ro["hist_xi1"][:n]) / ro["hist_xi1"][:n]) <= 1e-8 and r["status"] == 0
+    m.close()
+
+
 def test_emulated_nan_and_state_api(S, O, emu):
     specs = S.get_server_heat_specs(4, 5, 2, nu=2)
     flat = S.flatten_problem(*specs)

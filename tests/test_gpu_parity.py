@@ -136,7 +136,9 @@ def test_variants_match_oracle(S, O, name):
 def test_large_nx_lane_team_path(S, O):
     """BASELINE configs 3-5 (nx = 20 / 64): lane-team sweeps and lane-team node-local phases, CP and SP, against the oracle."""
     for specs, kw in ((S.get_server_heat_specs(6, 20, 2), {}), (S.get_server_heat_specs(5, 20, 3, p_ref=[0.2, 0.3, 0.5]), {}),
-                      (S.get_random_linear_specs(6, 64, 16), {})):
+                      (S.get_random_linear_specs(6, 64, 16), {}),
+                      # 127-node groups at nx = 64: the group-leaf sweep vector goes to global memory (config 5 at N = 15 does too)
+                      (S.get_random_linear_specs(9, 64, 16), {"split_stage": 1})):
         flat = S.flatten_problem(*specs)
         m = S.build_model(*specs, L_norm="auto", **kw)
         o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm

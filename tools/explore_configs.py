@@ -27,4 +27,4 @@ run("cfg3 N=9 nx=20 d=3", S.get_server_heat_specs(9, 20, 3, p_ref=[0.2, 0.3, 0.5
 run("cfg4 N=10 nx=20 d=2", S.get_server_heat_specs(10, 20, 2))
 run("cfg5-small N=9 nx=64 nu=16", S.get_random_linear_specs(9, 64, 16))
 if os.environ.get("BIG", "0") == "1":
-    run("cfg5 N=15 nx=64 nu=16", S.get_random_linear_specs(15, 64, 16), iters=4, check=False)
+    run("cfg5 N=15 nx=64 nu=16", S.get_random_linear_specs(15, 64, 16), iters=20, check=True)
