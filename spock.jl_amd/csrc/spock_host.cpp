@@ -208,10 +208,16 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     g.threads = r64(nl);
     g.team_local = 0;
     if (g.team && !g.team_reg && mode != MODE_FINALIZE && team_local_applies(dm)) {
-        // lane-team node-local phases: 256 threads = 256 / T teams, each with its scratch behind the sweep vectors
-        const int thr = 256, nteams = thr / g.team;
-        const long scr = (long)nteams * ((dm.ny + 2 * d) + nu + (2 + 2 * d) * g.team);
-        if ((team_doubles + scr) * 8 + tail <= budget) { g.team_local = 1; team_doubles += scr; g.threads = thr; }
+        // lane-team node-local phases: 512 threads = 512 / T teams (fewer rounds over the group's nodes: configs 3 / 4 /
+        // 5-small 381 / 188 / 335 -> 325 / 152 / 289 us per iteration against 256 threads), each team with its scratch
+        // behind the sweep vectors; 256 threads when that scratch does not fit
+        for (int thr = 512; thr >= 256 && !g.team_local; thr /= 2) {
+            if (const char *e = std::getenv("SPOCK_AMD_TL_THREADS")) thr = std::atoi(e);
+            const int nteams = thr / g.team;
+            const long scr = (long)nteams * ((dm.ny + 2 * d) + nu + (2 + 2 * d) * g.team);
+            if (nteams >= 1 && (team_doubles + scr) * 8 + tail <= budget) { g.team_local = 1; team_doubles += scr; g.threads = thr; }
+            if (std::getenv("SPOCK_AMD_TL_THREADS")) break;
+        }
     }
     if (g.team_local) {}
     // (Lane-team node-local phases on the register-resident sweep's (node, element) thread mapping were tried for the

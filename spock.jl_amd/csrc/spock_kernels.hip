@@ -345,7 +345,7 @@ static int launch_lop(const SpArgs &a_in, hipStream_t st) {
     int nthr = round64(dm.t0 > 0 ? (sub_thr > crown_thr ? sub_thr : crown_thr) : group_threads(dm.d, dm.N));
     SpArgs a = a_in;
     a.team = 0;
-    if (P::TEAMLOCAL) { a.team = 8; while (a.team < dm.nx || a.team < dm.nu) a.team *= 2; nthr = 256; }
+    if (P::TEAMLOCAL) { a.team = 8; while (a.team < dm.nx || a.team < dm.nu) a.team *= 2; nthr = 512; }
     hipLaunchKernelGGL((spock_sp_lop_kernel<P>), dim3(sp_lop_blocks(dm), a.batch), dim3(nthr), 0, st, a);
     return (int)hipGetLastError();
 }
