@@ -455,7 +455,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     for (auto &c : h->h_ctl) c.done = 1;
     if ((e = rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream))) return bail(e, "upload");
     if (alg == SPOCK_ALG_CP && h->fused && (e = choose_cp_sequence(h))) return bail(e, "timing the CP kernel sequences");
-    if (alg == SPOCK_ALG_SP) h->sp_fused = !launch_geometry(dm.t0 > 0 ? MODE_SUB_B : MODE_FULL, dm, h->batch).team_local && !std::getenv("SPOCK_AMD_SP_LOP");
+    if (alg == SPOCK_ALG_SP) h->sp_fused = !std::getenv("SPOCK_AMD_SP_LOP");
     if (alg == SPOCK_ALG_SP && (e = sp_init_state(h))) return bail(e, "SP state initialisation");
     if ((e = rt::sync(h->stream))) return bail(e, "hipStreamSynchronize");
     *out = h;

@@ -106,6 +106,7 @@ struct TState {
     double stg[kStageRegs];        // early-issued loads of the sweep inputs (spock_group.hpp)
     TLReg<P> tlr;                  // lane-team local phases
     double mx3[3];                 // residual maxima accumulated over the rounds of the lane-team phase B
+    double sp3[3];                 // ... and the SP inner products (tb_p2 SPM)
     // register-resident lane-team sweep (small compile-time shapes): this thread = (node tn_li, matrix row tn_r)
     // and keeps ITS rows of the sweep matrices of its node's stage for the whole kernel
     int tn_li, tn_r, tn_lvl, tn_pos;

@@ -420,7 +420,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         const unsigned bflags = crown_blk ? (flags | F_NO_SWEEP) : flags;   // the crown's x, u come from zbar
         if (team_local) {
             const bool from_zb = (bflags & F_NO_SWEEP) != 0;
-            x.each([&](int, TState<P> &s) { s.mx3[0] = s.mx3[1] = s.mx3[2] = 0.; });
+            x.each([&](int, TState<P> &s) { s.mx3[0] = s.mx3[1] = s.mx3[2] = 0.; s.sp3[0] = s.sp3[1] = s.sp3[2] = 0.; });
+            const double *dz_ = (SP_SUMS && a.dir) ? a.dir + (long)inst * a.stride_z : nullptr;
             for (int base = 0; base < nl_grp; base += nteams) {
                 x.each([&](int tid, TState<P> &s) {
                     const int tm = tid / TT, r = tid - tm * TT;
@@ -436,11 +437,14 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     const int tm = tid / TT, r = tid - tm * TT;
                     if (tm >= nteams) return;
                     const TeamNode tn = team_node(dm, d, base + tm, nl_grp, root_stage, root_pos, stages, crown);
-                    tb_p2(p, dm, M, z, v, zo, vo, tn, r, TT, tscr + tm * tscr_stride, ps, bflags, s.tlr, s.mx3);
+                    if constexpr (SP_SUMS) {
+                        if (a.sp_mode == 2) tb_p2<P, 2>(p, dm, M, z, v, zo, vo, tn, r, TT, tscr + tm * tscr_stride, ps, bflags, s.tlr, s.mx3, s.sp3, dz_, dz_ + dm.nz);
+                        else tb_p2<P, 1>(p, dm, M, z, v, zo, vo, tn, r, TT, tscr + tm * tscr_stride, ps, bflags, s.tlr, s.mx3, s.sp3);
+                    } else tb_p2(p, dm, M, z, v, zo, vo, tn, r, TT, tscr + tm * tscr_stride, ps, bflags, s.tlr, s.mx3);
                 });
                 x.barrier();
             }
-            x.each([&](int tid, TState<P> &s) { x.stash3(tid, s.mx3); });
+            x.each([&](int tid, TState<P> &s) { x.stash3(tid, s.mx3); if (SP_SUMS) x.stash_sum3(tid, s.sp3); });
         } else if constexpr (!SP_SUMS) {
             x.each([&](int tid, TState<P> &s) {
                 double mx[3] = {0., 0., 0.};
@@ -462,14 +466,20 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         const int slot = (MODE == MODE_FULL) ? 0 : g;
         x.reduce3();
         x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + tid] = x.red3(tid); });
-        if (SP_SUMS && !team_local) {
+        if (SP_SUMS) {
             x.reduce_sum3();
             x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + 4 + tid] = x.sum3(tid); });
             if (a.sp_mode == 2) {   // the termination residuals of the direction d itself (K1 step: dp = d), spock_sp.hpp: sp_ctl_cd
                 const double *dd_ = a.dir + (long)inst * a.stride_z;
                 x.each([&](int tid, TState<P> &s) {
                     double acc[4] = {0., 0., 0., 0.};
-                    if (s.active) lop_local(p, dm, M, nullptr, dd_, nullptr, s, gamma, sigma, acc);
+                    if (team_local) {   // T lanes per node, no exchange between lanes: rounds over the group's nodes
+                        const int tm = tid / TT, r = tid - tm * TT;
+                        for (int li = tm; li < nl_grp && tm < nteams; li += nteams) {
+                            const TeamNode tn = team_node(dm, d, li, nl_grp, root_stage, root_pos, stages, crown);
+                            tlop(p, dm, M, nullptr, dd_, nullptr, tn, r, gamma, sigma, acc);
+                        }
+                    } else if (s.active) lop_local(p, dm, M, nullptr, dd_, nullptr, s, gamma, sigma, acc);
                     const double mx[3] = {acc[2], acc[3], 0.};
                     x.stash3(tid, mx);
                 });

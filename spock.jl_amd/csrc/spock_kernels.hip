@@ -121,8 +121,8 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
                            : mode == MODE_CROWN ? (const void *)spock_group_kernel<P, MODE_CROWN>
                            : mode == MODE_SUB_B ? (const void *)spock_group_kernel<P, MODE_SUB_B>
                            : mode == MODE_SUB_BA ? (const void *)spock_group_kernel<P, MODE_SUB_BA>
-                           : mode == MODE_SUB_B_SP ? (const void *)spock_group_kernel<P, P::TEAMLOCAL ? MODE_SUB_B : MODE_SUB_B_SP>
-                           : mode == MODE_FULL_SP ? (const void *)spock_group_kernel<P, P::TEAMLOCAL ? MODE_FULL : MODE_FULL_SP>
+                           : mode == MODE_SUB_B_SP ? (const void *)spock_group_kernel<P, MODE_SUB_B_SP>
+                           : mode == MODE_FULL_SP ? (const void *)spock_group_kernel<P, MODE_FULL_SP>
                                                 : (const void *)spock_group_kernel<P, MODE_FINALIZE>;
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
@@ -138,14 +138,8 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
         case MODE_SUB_BA:
             hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_BA>), grid, block, lds, st, a);
             break;
-        case MODE_SUB_B_SP:
-            if constexpr (P::TEAMLOCAL) return (int)hipErrorInvalidConfiguration;   // lane-team handles keep the LOP kernels
-            else hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_B_SP>), grid, block, lds, st, a);
-            break;
-        case MODE_FULL_SP:
-            if constexpr (P::TEAMLOCAL) return (int)hipErrorInvalidConfiguration;
-            else hipLaunchKernelGGL((spock_group_kernel<P, MODE_FULL_SP>), grid, block, lds, st, a);
-            break;
+        case MODE_SUB_B_SP: hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_B_SP>), grid, block, lds, st, a); break;
+        case MODE_FULL_SP: hipLaunchKernelGGL((spock_group_kernel<P, MODE_FULL_SP>), grid, block, lds, st, a); break;
         default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();

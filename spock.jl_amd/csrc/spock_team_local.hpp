@@ -180,10 +180,12 @@ SPK_DEV void tb_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
 }
 
 // phase B, part 2: finish the Moreau step (prox_h_conj!), store vbar, accumulate the residual maxima
-template <class P>
+// SPM: the SP driver's inner products with the residual of this evaluation, as in b_local (spock_device.hpp)
+template <class P, int SPM = 0>
 SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z, const double *__restrict__ v,
                    const double *zb, double *__restrict__ vo, const TeamNode &t, int r, int T, const double *S,
-                   const ProxScal &ps, unsigned flags, const TLReg<P> &g, double *mx) {
+                   const ProxScal &ps, unsigned flags, const TLReg<P> &g, double *mx, double *sp = nullptr,
+                   const double *dirz = nullptr, const double *dirv = nullptr) {
     if (!t.active) return;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), nxu = nx + nu, m = ny + 2 * d;
     const int i = t.node;
@@ -192,6 +194,16 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
     const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb;
     const double *red = S + m + nu;
     double m1 = mx[0], m2 = mx[1], m3 = mx[2];
+    double sp_z = 0., sp_v = 0., sp_d = 0.;
+    const double gm = ps.gamma;
+    auto acc_z = [&](int iz, double dz, double x1) {
+        if (SPM >= 1) sp_z += dz * x1;
+        if (SPM == 2) sp_d -= dirz[iz] * (dz - sg * (x1 - nig * dz));
+    };
+    auto acc_v = [&](int iv, double dv, double x2) {
+        if (SPM >= 1) sp_v += dv * x2;
+        if (SPM == 2) sp_d -= dirv[iv] * (dv - gm * (x2 - nis * dv));
+    };
     // ---- v2 (every lane, redundantly: a handful of flops) and v1 (lane r < ny)
     double bw = 0., bdz = 0.;
     for (int k = 0; k < ny; ++k) { bw += red[0 * T + k]; bdz += red[1 * T + k]; }
@@ -206,6 +218,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
         m2 = spk_max_nan(m2, fabs(x2));
         const double x1s = dv2 + nig * dzs;                            // xi_1 on s_i
         m1 = spk_max_nan(m1, fabs(x1s));
+        acc_v(dm.o2 + i, dv2, x2); acc_z(dm.zs + i, dzs, x1s);
         if (wx) m3 = spk_max_nan(m3, fabs(x2 + x1s));
     }
     if (r < ny) {
@@ -222,6 +235,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
         m2 = spk_max_nan(m2, fabs(x2k));
         const double x1k = (dv1 - bb[r] * dv2) + nig * g.dzy;
         m1 = spk_max_nan(m1, fabs(x1k));
+        acc_v(i * ny + r, dv1, x2k); acc_z(dm.zy + i * ny + r, g.dzy, x1k);
         if (wx) m3 = spk_max_nan(m3, fabs((x2k - bb[r] * x2) + x1k));
     }
     // ---- v7: box on (x_i, u_i)
@@ -233,6 +247,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
         vo[dm.o7 + i * nxu + r] = nvv;
         ltx = nvv - vin; lxx = g.dzx + nis * ltx;
         m2 = spk_max_nan(m2, fabs(lxx));
+        acc_v(dm.o7 + i * nxu + r, ltx, lxx);
     }
     if (r < nu) {
         const double vin = v[dm.o7 + i * nxu + nx + r];
@@ -241,6 +256,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
         vo[dm.o7 + i * nxu + nx + r] = nvv;
         ltu = nvv - vin; lxu = g.dzu + nis * ltu;
         m2 = spk_max_nan(m2, fabs(lxu));
+        acc_v(dm.o7 + i * nxu + nx + r, ltu, lxu);
     }
     // ---- per child: (v6; v3, v4, v5) in SOC(nx + nu + 2)   (implicit_l.jl:854-900, :928-933)
     SPK_UNROLL for (int c = 0; c < d; ++c) {
@@ -267,6 +283,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
             m2 = spk_max_nan(m2, fabs(x26)); m2 = spk_max_nan(m2, fabs(x25));
             const double x1t = (0.5 * dv5 + 0.5 * dv6) + nig * dzt;   // xi_1 on tau_j
             m1 = spk_max_nan(m1, fabs(x1t));
+            acc_v(dm.o6 + jn, dv6, x26); acc_v(dm.o5 + jn, dv5, x25); acc_z(dm.zt + jn, dzt, x1t);
             if (wx) m3 = spk_max_nan(m3, fabs((0.5 * x25 + 0.5 * x26) + x1t));
         }
         if (r < nx) {
@@ -275,6 +292,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
             vo[dm.o3 + jn * nx + r] = pj;
             const double dv = pj - v[dm.o3 + jn * nx + r], xx = g.l3[c] + nis * dv;
             m2 = spk_max_nan(m2, fabs(xx));
+            acc_v(dm.o3 + jn * nx + r, dv, xx);
             ltx += SQ[r + r * nx] * dv; lxx += SQ[r + r * nx] * xx;
         }
         if (r < nu) {
@@ -283,6 +301,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
             vo[dm.o4 + jn * nu + r] = pj;
             const double dv = pj - v[dm.o4 + jn * nu + r], xx = g.l4[c] + nis * dv;
             m2 = spk_max_nan(m2, fabs(xx));
+            acc_v(dm.o4 + jn * nu + r, dv, xx);
             ltu += SR[r + r * nu] * dv; lxu += SR[r + r * nu] * xx;
         }
         // ---- leaf child: (v13; v11, v12) in SOC(nx + 2), v14 in the x box   (implicit_l.jl:752-810, :934-939)
@@ -310,6 +329,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
                 m2 = spk_max_nan(m2, fabs(x213)); m2 = spk_max_nan(m2, fabs(x212));
                 const double x1s2 = (0.5 * dv12 + 0.5 * dv13) + nig * dzs2;   // xi_1 on s_leaf
                 m1 = spk_max_nan(m1, fabs(x1s2));
+                acc_v(dm.o13 + li, dv13, x213); acc_v(dm.o12 + li, dv12, x212); acc_z(dm.zs + j, dzs2, x1s2);
                 if (wx) m3 = spk_max_nan(m3, fabs((0.5 * x212 + 0.5 * x213) + x1s2));
             }
             if (r < nx) {
@@ -325,6 +345,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
                 m2 = spk_max_nan(m2, fabs(x214));
                 const double x1 = (dv14 + SN[r + r * nx] * dv11) + nig * g.dl[c];   // x_leaf = v14 + sqrtQN v11
                 m1 = spk_max_nan(m1, fabs(x1));
+                acc_v(dm.o11 + li * nx + r, dv11, x211); acc_v(dm.o14 + li * nx + r, dv14, x214); acc_z(dm.zx + j * nx + r, g.dl[c], x1);
                 if (wx) m3 = spk_max_nan(m3, fabs((x214 + SN[r + r * nx] * x211) + x1));
             }
         }
@@ -332,14 +353,18 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
     if (r < nx) {
         const double x1 = ltx + nig * g.dzx;
         m1 = spk_max_nan(m1, fabs(x1));
+        acc_z(dm.zx + i * nx + r, g.dzx, x1);
         if (wx) m3 = spk_max_nan(m3, fabs(lxx + x1));
     }
     if (r < nu) {
         const double x1 = ltu + nig * g.dzu;
         m1 = spk_max_nan(m1, fabs(x1));
+        acc_z(dm.zu + i * nu + r, g.dzu, x1);
         if (wx) m3 = spk_max_nan(m3, fabs(lxu + x1));
     }
     mx[0] = m1; mx[1] = m2; mx[2] = m3;
+    if (SPM >= 1) { sp[0] += sp_z; sp[1] += sp_v; }
+    if (SPM == 2) sp[2] += sp_d;
 }
 
 // ---------------------------------------------------------------------------------------------------
