@@ -81,7 +81,11 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 }
                 x.stash3(tid, mx);
             });
+            // Every thread reads the control block itself, and thread 0 is about to UPDATE it (pending, counters): all
+            // snapshots must have been taken before that, or a late wave sees the new `pending` and takes the other branch
+            // -- from then on the workgroup's barriers pair up out of phase.  (reduce3 starts with a barrier.)
             if (snap.pending && !snap.done) x.reduce3();   // workgroup-parallel max over the per-workgroup residual maxima
+            else x.barrier();
             x.each([&](int tid, TState<P> &) {
                 if (tid == 0) {
                     double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
@@ -153,8 +157,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
     // Every first touch of data another kernel wrote is a cold miss (~1.5-2 us: the writer sat on another XCD).  Issue the
     // matrix-row loads above and the sweep inputs staged here in registers back to back, before waiting for any of them.
-    // (Hoisting them above the control section as well was tried: no measurable gain, and keeping that much state live
-    // across it produced wrong iterates on the GPU in the 512-thread crown -- the control section stays first.)
+    // (Hoisting them above the control section as well was tried: no measurable gain.  The wrong iterates seen with that
+    // variant were not its fault: they came from the control-block snapshot race fixed above, which the changed timing exposed.)
     //   crown : c_i / e_i of the crown nodes (cbuf) and q of the subtree roots (qroot)
     //   SUB_B : d_i of the subtree's nodes (dbuf)
     const int st_n1 = (MODE == MODE_CROWN) ? nl_grp * nxu : (((MODE == MODE_SUB_B || MODE == MODE_SUB_BA) && !crown_blk) ? nl_grp * p.nu() : 0);

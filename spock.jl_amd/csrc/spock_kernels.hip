@@ -51,7 +51,7 @@ struct GpuExec {
     __device__ __forceinline__ double red3(int k) const { return __longlong_as_double((long long)red[k]); }
     // deterministic sums over the workgroup (SP inner products): fixed shuffle tree per wave, then the waves in order
     double sm[3];
-    double *sums;   // LDS [3][8 waves] + [3] results
+    double *sums;   // LDS [3][16 waves] + [3] results
     __device__ __forceinline__ void stash_sum3(int, const double *v) { sm[0] = v[0]; sm[1] = v[1]; sm[2] = v[2]; }
     __device__ __forceinline__ void reduce_sum3() {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
@@ -60,17 +60,17 @@ struct GpuExec {
             double v = sm[k];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) sums[k * 8 + wave] = v;
+            if (lane == 0) sums[k * 16 + wave] = v;
         }
         __syncthreads();
         if (threadIdx.x < 3) {
-            double v = sums[threadIdx.x * 8];
-            for (int w = 1; w < nw; ++w) v += sums[threadIdx.x * 8 + w];
-            sums[24 + threadIdx.x] = v;
+            double v = sums[threadIdx.x * 16];
+            for (int w = 1; w < nw; ++w) v += sums[threadIdx.x * 16 + w];
+            sums[48 + threadIdx.x] = v;
         }
         __syncthreads();
     }
-    __device__ __forceinline__ double sum3(int k) const { return sums[24 + k]; }
+    __device__ __forceinline__ double sum3(int k) const { return sums[48 + k]; }
 };
 
 #ifdef SPOCK_WAVES_PER_EU   // experiment builds only
@@ -80,7 +80,7 @@ struct GpuExec {
 #endif
 
 template <class P, int MODE>
-__global__ void __launch_bounds__(512) SPK_KERNEL_ATTR spock_group_kernel(const KArgs a) {
+__global__ void __launch_bounds__(P::TEAMLOCAL ? 1024 : 512) SPK_KERNEL_ATTR spock_group_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpuExec<P> x;
     x.ex = smem;
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(512) SPK_KERNEL_ATTR spock_group_kernel(const 
     x.fl = reinterpret_cast<int *>(x.red + 3);
     x.stamps = reinterpret_cast<unsigned long long *>(smem + a.ex_doubles + 4);
     x.sums = smem + a.ex_doubles + 4 + 128;
-    x.lm = smem + a.ex_doubles + 4 + 128 + 32;
+    x.lm = smem + a.ex_doubles + 4 + 128 + 64;
     const bool wave_stamps = (a.flags & F_DBG_STAMPS) && a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && MODE != MODE_FINALIZE;
     unsigned long long *wd = a.dbg ? a.dbg + (long)(MODE == MODE_SUB_A ? 0 : (MODE == MODE_CROWN ? 1 : 2)) * 128 : nullptr;
     if (wave_stamps) wd[2 * (40 + (threadIdx.x >> 6)) + 1] = __builtin_amdgcn_s_memrealtime();
@@ -101,7 +101,7 @@ static inline int round64(int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; }
 template <class P>
 static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     const LaunchGeo g = launch_geometry(mode, a_in.dm, a_in.batch);
-    if (g.threads > 512) return (int)hipErrorInvalidConfiguration;
+    if (g.threads > (P::TEAMLOCAL ? 1024 : 512)) return (int)hipErrorInvalidConfiguration;
     KArgs a = a_in;
     // LDS-staged sweep matrices pay off when many workgroups hide the staging copy (batched regime: +18 % at 512
     // instances); with a handful of workgroups the copy is pure latency in front of the sweep (+3 us per kernel)

@@ -85,7 +85,7 @@ static int launch_variant(int mode, const KArgs &a_in) {
     a.xl_global = (g.team && g.xl_global && a.xlbuf) ? 1 : 0; a.xl_stride = g.xl_stride;
     if (g.team && g.xl_global && !a.xlbuf) return 9;
     const int thr = g.threads, gx = g.grid_x;
-    if (thr > 512) return 9;
+    if (thr > (P::TEAMLOCAL ? 1024 : 512)) return 9;
     switch (mode) {
         case MODE_FULL: run_blocks<P, MODE_FULL>(a, gx, thr); break;
         case MODE_SUB_A: run_blocks<P, MODE_SUB_A>(a, gx, thr); break;
