@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
         if (a.op == SP_CTL_A && ctl.done == 2 && threadIdx.x == 0) ctl.done = 1;   // the final state update has run
         return;
     }
-    __shared__ double red[6 * 16];
+    __shared__ double red[12 * 16];
     SpCtl &c = a.sp[inst];
     const double *pf = a.partF + (long)inst * a.n_partF * kSpSums, *pl = a.partL + (long)inst * a.n_partL * kSpSums;
     double f[6] = {0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
@@ -294,13 +294,31 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
         for (int r = threadIdx.x; r < a.n_partL; r += kCtlThreads) {
             m[0] = spk_max_nan(m[0], pl[(long)r * kSpSums + 2]); m[1] = spk_max_nan(m[1], pl[(long)r * kSpSums + 3]);
         }
-    block_reduce<6, false>(f, red);
-    __syncthreads();
-    block_reduce<2, false>(l, red);
-    __syncthreads();
-    block_reduce<2, true>(m, red);
-    __syncthreads();
-    block_reduce<2, true>(g2, red);
+    {   // one pass for all twelve values (eight sums, four maxima): fixed shuffle tree per wave, then the waves in order
+        double val[12] = {f[0], f[1], f[2], f[3], f[4], f[5], l[0], l[1], m[0], m[1], g2[0], g2[1]};
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (kCtlThreads + 63) >> 6;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            double x = val[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_down(x, off, 64);
+                x = (k >= 8) ? spk_max_nan(x, o) : x + o;
+            }
+            if (lane == 0) red[k * 16 + wave] = x;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                double x = red[k * 16];
+                for (int w = 1; w < nw; ++w) x = (k >= 8) ? spk_max_nan(x, red[k * 16 + w]) : x + red[k * 16 + w];
+                val[k] = x;
+            }
+            for (int k = 0; k < 6; ++k) f[k] = val[k];
+            l[0] = val[6]; l[1] = val[7]; m[0] = val[8]; m[1] = val[9]; g2[0] = val[10]; g2[1] = val[11];
+        }
+    }
     if (threadIdx.x == 0) {
         double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
         if (a.op == SP_CTL_CD) sp_ctl_cd(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], hist, a.hist_cap);
