@@ -4,20 +4,19 @@
 //   spock_dot / norm   /root/reference/src/model_dynamics/implicit_l.jl:485-557
 //
 // One SP iteration on the device (driver: spock_abi.cpp; every kernel exits at once for a finished instance):
-//   T(Z) -> ZB                                   the three CP kernels (spock_group.hpp)
+//   T(Z) -> ZB     the three CP kernels; phase B also accumulates <r, P r> (b_local / tb_p2 with SPM = 1)      (sp.jl:34-51)
 //   FLAT1   r = Z - ZB, dr = r - r_old, new Anderson columns, Gram sums      (anderson.jl:13-65)
-//   LOP     <r, P r>                                                          (sp.jl:34-51)
-//   CTL_A   rnorm, Gram-Schmidt coefficients r2, r3, shift of R              (anderson.jl:46-50,76-88)
+//   CTL_A   rnorm, Gram-Schmidt coefficients r2, r3, shift of R; keeps T(Z)'s CP residuals   (anderson.jl:46-50,76-88)
 //   FLAT2   Q1 = dr - r2 Q2 - r3 Q3, its norm, Q'r                           (anderson.jl:88-110)
 //   CTL_B   R11, gamma = R^-1 Q'r                                            (anderson.jl:94-113)
 //   FLAT3   Q1 /= rho, d = -r - MP gamma, candidate W = Z + d                (anderson.jl:116-122, sp.jl:118-131)
-//   T(W) -> WB
-//   FLAT4   rt = W - WB                                                      (sp.jl:155-160)
-//   LOP     <rt, P rt>, <rt, P d>                                            (sp.jl:163, :420-434)
-//   CTL_C   K1 / K2 / fall-back decision, r_safe, backtrack count           (sp.jl:411-446)
-//   FLAT5   Z <- W | Z - coef rt | ZB ;  dp = Z - Z_old                      (sp.jl:166-222, :270-281)
-//   LOP     xi_1 = |L' dp_v - dp_z / gamma|_inf, xi_2 = |L dp_z - dp_v / sigma|_inf   (sp.jl:283-293)
-//   CTL_D   termination test, history, counters                             (sp.jl:295-344, :464)
+//   T(W) -> WB     phase B also accumulates <rt, P rt>, <rt, P d> (SPM = 2) and forms the termination residuals of d
+//   CTL_CD  K1 / K2 / fall-back decision, r_safe, backtrack count (sp.jl:411-446); termination test, history,
+//           counters (sp.jl:295-344, :464) with the residuals of dp taken by linearity from the two evaluations
+//   FLAT5   Z <- W | Z - coef (W - WB) | ZB ;  dp = Z - Z_old                (sp.jl:166-222, :270-281)
+// = 13 launches.  The first version (SPOCK_AMD_SP_LOP=1, still built and tested) used separate passes instead:
+//   ... T(Z), FLAT1, LOP <r, P r>, CTL_A, FLAT2, CTL_B, FLAT3, T(W), FLAT4 rt = W - WB, LOP <rt, P rt>, <rt, P d>,
+//   CTL_C, FLAT5, LOP xi_1, xi_2 of dp (sp.jl:283-293), CTL_D = 18 launches.
 //
 // Differences from the reference that leave the iterates unchanged: the Anderson buffers are circular
 // (no column shifting), MR is not stored (it only ever feeds Q), a rejected candidate is
