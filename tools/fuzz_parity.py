@@ -74,6 +74,18 @@ for case in range(n_cases):
         zz = np.asarray(m.solver_state.z).reshape(B, -1)[0]
         errs.append(relerr(zz, o.z))
         m.close()
+        if rng.random() < 0.3 and flat.n <= 400:   # whole solves: the device-side termination logic, both rules, warm start
+            log = bool(rng.random() < 0.5)
+            mt = S.build_model(*specs, L_norm=float(o.L_norm), max_iter=1500, lib_path=lib, **kw)
+            ot = O.Oracle(flat, O.CP); ot.L_norm = o.L_norm
+            for xs in (x0, 1.2 * x0):
+                rt = S.solve_model(mt, np.tile(xs, (B, 1)) if B > 1 else xs, tol=1e-3, verbose=S.LOG if log else S.SILENT)
+                rot = ot.solve(xs, tol=1e-3, verbose=O.LOG if log else O.SILENT, max_iter=1500)
+                rt0 = rt[0] if isinstance(rt, list) else rt
+                if (rt0["iterations"], rt0["status"]) != (rot["iterations"], rot["status"]):
+                    errs.append(1.0)
+                errs.append(relerr(np.asarray(mt.solver_state.z).reshape(B, -1)[0], ot.z) * 1e-1)
+            mt.close(); desc += " +solve" + ("LOG" if log else "")
         if rng.random() < 0.35:   # the SP driver on the same problem: first iterations of the residual history
             ms = S.build_model(*specs, S.SolverOptions(S.SP, None), L_norm=float(o.L_norm), max_iter=12, lib_path=lib, **kw)
             osp = O.Oracle(flat, O.SP); osp.L_norm = o.L_norm
