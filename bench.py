@@ -196,6 +196,19 @@ def main():
                 single["cpu_oracle_ms_to_tol_nu5"] = round(dt5 * 1e3, 1)
                 single["cpu_oracle_iterations_nu5"] = ro["iterations"]
             out["single_instance"] = single
+            # problems/s: 64 independent instances of the convergent (nu = 5) tree, different x0, solved to tol 1e-3 as one batch
+            probs = {}
+            X = 0.1 * (1.0 + 0.01 * np.arange(64))[:, None] * np.ones((64, NX))
+            for name, alg in (("cp", S.CP), ("sp", S.SP)):
+                mb = S.build_model(*specs5, S.SolverOptions(alg, None), batch=64, device=local_rank)
+                S.solve_model(mb, X, tol=1e-3); mb.reset()
+                torch.cuda.synchronize(); t = time.perf_counter(); rb = S.solve_model(mb, X, tol=1e-3); torch.cuda.synchronize()
+                dtb = time.perf_counter() - t
+                assert all(q["status"] == 0 for q in rb)
+                probs[name] = {"instances": 64, "ms": round(dtb * 1e3, 2), "problems_per_s": round(64 / dtb, 1),
+                               "iterations_max": max(q["iterations"] for q in rb)}
+                mb.close()
+            out["problems_to_tol_1e-3_nu5"] = probs
 
     if rank == 0:
         print(json.dumps(out), flush=True)
