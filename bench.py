@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="problem instances per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="problem instances per GPU (4.4 MB of state each)")
     ap.add_argument("--iters", type=int, default=100, help="CP iterations per step (even)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true")

@@ -23,12 +23,12 @@ def kind(name):
     return MODES.get(m)
 
 
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
-shutil.copy(stats[0], os.path.join(dst, f"bench_b{B}_kernel_stats.csv"))
+newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)   # gpurun_out/ accumulates earlier runs
+shutil.copy(newest(os.path.join(src, "stats", "**", "*kernel_stats.csv")), os.path.join(dst, f"bench_b{B}_kernel_stats.csv"))
 out = {"config": f"bench.py --batch {B} (server_heat nx=5 nu=2 d=2 N=13), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes",
        "kernels": {}, "batch": B}
 for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = newest(os.path.join(src, sub, "**", "*counter_collection.csv"))
     rows = list(csv.DictReader(open(f)))
     keep = [r for r in rows if kind(r["Kernel_Name"])]
     with open(os.path.join(dst, f"{sub}_counter_collection.csv"), "w", newline="") as g:
