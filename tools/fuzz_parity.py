@@ -22,6 +22,8 @@ def random_case():
     d = int(rng.choice([2, 2, 2, 3, 4]))
     N = int(rng.integers(2, {2: 10, 3: 7, 4: 5}[d] + 1))
     nx = int(rng.choice([1, 2, 3, 4, 5, 5, 5, 6, 8, 9, 12, 20]))
+    if os.environ.get("SPOCK_FUZZ_LARGE"):   # lane-team kernels at awkward sizes
+        nx = int(rng.choice([9, 16, 17, 24, 32, 33, 48, 64])); N = min(N, 6 if d == 2 else 4)
     nu = int(rng.integers(1, nx + 1))
     if rng.random() < 0.25 and nx in (5,):
         nu = int(rng.choice([2, 5]))
