@@ -1,7 +1,7 @@
 """Exploration (not a test): every BASELINE.json configuration once -- build, a few CP iterations, time per iteration,
 and a spot check of the operator T against the oracle."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import spock_jl_amd as S
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """Exploration (not a test): BASELINE config 4 -- mpc_simulation.jl (nx = nu = 20, d = 2, N = 10, SP, tol 1e-3, 20 steps)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import spock_jl_amd as S
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """Exploration (not a test): SP (SuperMann) timing on the GPU vs the oracle."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import spock_jl_amd as S
 from oracle import oracle as O

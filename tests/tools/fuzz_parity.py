@@ -1,10 +1,10 @@
 """Randomised parity sweep (not a test, run on the GPU box): random problem shapes, costs, risk measures, split stages and
 batch sizes; operator T and a short CP / SP run against the oracle.  Prints one line per failure and a summary.
 
-    python tools/fuzz_parity.py [n_cases] [seed]
+    python tests/tools/fuzz_parity.py [n_cases] [seed]
 """
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import spock_jl_amd as S
 from oracle import oracle as O
