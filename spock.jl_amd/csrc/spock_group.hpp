@@ -457,11 +457,23 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
             });
         } else {   // SP driver: the inner products with the residual of this evaluation ride along (b_local, SPM)
             const double *dz_ = a.dir ? a.dir + (long)inst * a.stride_z : nullptr;
+            // Latency regime (register-resident sweep: T threads per node, so phase B keeps one wave busy and leaves the
+            // others idle): the residuals of the direction d (below) are formed AT THE SAME TIME by the second wave --
+            // thread 64 + li does node li -- instead of after phase B by the first.
+            const int shadow0 = 64;
+            const bool lop_shadow = a.sp_mode == 2 && nl_grp <= 64 && nthr >= 128;
             x.each([&](int tid, TState<P> &s) {
                 double mx[3] = {0., 0., 0.}, sp[3] = {0., 0., 0.};
+                s.mx3[0] = s.mx3[1] = s.mx3[2] = 0.;
                 if (s.active) {
                     if (a.sp_mode == 2) b_local<P, 2>(p, dm, M, z, v, zo, vo, s, ps, bflags, mx, sp, dz_, dz_ + dm.nz);
                     else b_local<P, 1>(p, dm, M, z, v, zo, vo, s, ps, bflags, mx, sp);
+                } else if (lop_shadow && tid >= shadow0 && tid < shadow0 + nl_grp) {
+                    TState<P> sh;
+                    init_geometry(p, dm, tid - shadow0, root_stage, root_pos, stages, crown, sh);
+                    double acc[4] = {0., 0., 0., 0.};
+                    if (sh.active) lop_local(p, dm, M, nullptr, dz_, nullptr, sh, gamma, sigma, acc);
+                    s.mx3[0] = acc[2]; s.mx3[1] = acc[3];
                 }
                 x.stash3(tid, mx);
                 x.stash_sum3(tid, sp);
@@ -475,9 +487,11 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
             x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + 4 + tid] = x.sum3(tid); });
             if (a.sp_mode == 2) {   // the termination residuals of the direction d itself (K1 step: dp = d), spock_sp.hpp: sp_ctl_cd
                 const double *dd_ = a.dir + (long)inst * a.stride_z;
+                const bool lop_shadow = !team_local && nl_grp <= 64 && nthr >= 128;   // done next to phase B (above)
                 x.each([&](int tid, TState<P> &s) {
                     double acc[4] = {0., 0., 0., 0.};
-                    if (team_local) {   // T lanes per node, no exchange between lanes: rounds over the group's nodes
+                    if (lop_shadow) { acc[2] = s.mx3[0]; acc[3] = s.mx3[1]; }
+                    else if (team_local) {   // T lanes per node, no exchange between lanes: rounds over the group's nodes
                         const int tm = tid / TT, r = tid - tm * TT;
                         for (int li = tm; li < nl_grp && tm < nteams; li += nteams) {
                             const TeamNode tn = team_node(dm, d, li, nl_grp, root_stage, root_pos, stages, crown);
