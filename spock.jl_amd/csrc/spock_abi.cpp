@@ -33,6 +33,7 @@ struct spock_handle_s {
     void *stream = nullptr, *ev0 = nullptr, *ev1 = nullptr, *graph = nullptr;
     // device memory
     double *d_mats = nullptr, *d_z[3] = {nullptr, nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}, *d_v2x = nullptr;
+    bool lat_regime = false;   // few workgroups in flight (register-resident sweep): SUB_B runs as MODE_SUB_B_LAT
     bool sp_fused = false;   // SP: the inner products with the residuals come out of phase B instead of out of LOP kernels
     bool fused = false;   // CP iteration = CROWN + SUB_BA (after one SUB_A) instead of SUB_A + CROWN + SUB_B
     double *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_partials = nullptr, *d_x0 = nullptr, *d_hist = nullptr;
@@ -115,7 +116,7 @@ int launch_cp_iteration(spock_handle_s *h, int k, unsigned flags = 0) {
     int e = 0;
     if (!h->fused) e = launch_group(MODE_SUB_A, a, h->stream);
     if (e == 0) e = launch_group(MODE_CROWN, a, h->stream);
-    if (e == 0) e = launch_group(h->fused ? MODE_SUB_BA : MODE_SUB_B, a, h->stream);
+    if (e == 0) e = launch_group(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), a, h->stream);
     return e;
 }
 int cp_prologue(spock_handle_s *h, unsigned flags = 0) {
@@ -429,6 +430,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         for (int k = 0; k < 2; ++k) if ((e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
         if ((e = dev_alloc(h, &h->d_v2x, B * (size_t)dm.nsub))) return bail(e, "hipMalloc(state)");
         h->fused = dm.t0 > 0;
+        h->lat_regime = dm.t0 > 0 && launch_geometry(MODE_SUB_B, dm, h->batch).team_reg != 0;
     } else {
         const size_t nr = (size_t)dm.nz + dm.nv;
         for (int k = 0; k < 10; ++k) if ((e = dev_alloc(h, &h->s_vec[k], B * nr))) return bail(e, "hipMalloc(SP state)");
@@ -763,7 +765,7 @@ int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_
         if (!split) { seq.push_back(MODE_FULL); seq_it.push_back(it); continue; }
         if (!h->fused) { seq.push_back(MODE_SUB_A); seq_it.push_back(it); }
         seq.push_back(MODE_CROWN); seq_it.push_back(it);
-        seq.push_back(h->fused ? MODE_SUB_BA : MODE_SUB_B); seq_it.push_back(it);
+        seq.push_back(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B)); seq_it.push_back(it);
     }
     std::vector<void *> ev(seq.size() * 2, nullptr);
     for (auto &e : ev) RTCHECK(rt::event_create(&e));

@@ -518,7 +518,10 @@ SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, const double *
 //   <r, P r> = sum_z dz (dz - gamma L'dv) + sum_v dv (dv - sigma L dz) = -gamma sum_z dz xi_1 - sigma sum_v dv xi_2
 //   <r, P d> = -sum_z d_z (dz - sigma L'dv) - sum_v d_v (dv - gamma L dz)        (implicit_l.jl:485-516)
 //   SPM 1: sp[0] += sum_z dz xi_1, sp[1] += sum_v dv xi_2;   SPM 2: also sp[2] += <r, P d> with d = (dirz, dirv)
-template <class P, int SPM = 0>
+// PART: 0 everything; 1 without the leaf-children blocks; 2 only the leaf-children blocks.  The leaf blocks share nothing
+// with the rest but the residual maxima and the SP sums (both reduced over the workgroup anyway), so in the single-instance
+// regime, where the workgroup has idle waves during phase B, a second thread does them at the same time (spock_group.hpp).
+template <class P, int SPM = 0, int PART = 0>
 SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
                      const double *__restrict__ v, const double *zb, double *__restrict__ vo, TState<P> &s,
                      const ProxScal &ps, unsigned flags, double *mx, double *sp = nullptr, const double *dirz = nullptr,
@@ -528,6 +531,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
     const double sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0, wx = ps.want_xi;
     double m1 = mx[0], m2 = mx[1], m3 = mx[2];
+    constexpr bool MAIN = (PART != 2), LEAF = (PART != 1);
     double sp_z = 0., sp_v = 0., sp_d = 0.;
     const double gm = ps.gamma;
     // one z entry (index iz, dz, xi_1) / one v entry (index iv, dv, xi_2) of the sums above
@@ -550,21 +554,23 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
     }
     // w = 2 zbar - z (cp.jl:23-24) and dz = zbar - z on x_i, u_i
     double wxv[P::MAXNX], dzx[P::MAXNX], wuv[P::MAXNU], dzu[P::MAXNU];
-    SPK_UNROLL for (int k = 0; k < nx; ++k) {
-        const double zi = z[dm.zx + i * nx + k];
-        wxv[k] = wz ? s.xb[k] : 2. * s.xb[k] + -1. * zi;
-        dzx[k] = s.xb[k] - zi;
-    }
-    SPK_UNROLL for (int k = 0; k < nu; ++k) {
-        const double zi = z[dm.zu + i * nu + k];
-        wuv[k] = wz ? s.ub[k] : 2. * s.ub[k] + -1. * zi;
-        dzu[k] = s.ub[k] - zi;
+    if (MAIN) {
+        SPK_UNROLL for (int k = 0; k < nx; ++k) {
+            const double zi = z[dm.zx + i * nx + k];
+            wxv[k] = wz ? s.xb[k] : 2. * s.xb[k] + -1. * zi;
+            dzx[k] = s.xb[k] - zi;
+        }
+        SPK_UNROLL for (int k = 0; k < nu; ++k) {
+            const double zi = z[dm.zu + i * nu + k];
+            wuv[k] = wz ? s.ub[k] : 2. * s.ub[k] + -1. * zi;
+            dzu[k] = s.ub[k] - zi;
+        }
     }
     // accumulators of (L' dv) and (L' xi_2) on x_i, u_i
     double ltx[P::MAXNX], ltu[P::MAXNU], lxx[P::MAXNX], lxu[P::MAXNU];
 
     // ---- v1, v2 : risk-measure block of node i -------------------------------------------------
-    {
+    if (MAIN) {
         const MatPtr bb = M + dm.mb;
         double wy[P::MAXNY], dzy[P::MAXNY], t1[P::MAXNY], pr[P::MAXNY];
         double bw = 0., bdz = 0.;
@@ -649,7 +655,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         if (wx) m3 = spk_max_nan(m3, fabs(x2 + x1s));
     }
     // ---- v7 : box on (x_i, u_i)  (implicit_l.jl:275-282, constraints.jl:38-54) ---------------------
-    {
+    if (MAIN) {
         SPK_UNROLL for (int k = 0; k < nxu; ++k) {
             const bool isx = k < nx;
             const double wv = isx ? wxv[k] : wuv[k - nx];
@@ -673,6 +679,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
     // ---- per child j: (v6_j; v3_j, v4_j, v5_j) in SOC(nx+nu+2)  (implicit_l.jl:226-272, :854-900) ---
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = s.c0 + c, jn = j - 1;
+        if (MAIN) {
         const MatPtr SQ = M + dm.mSqQ + (P::SHARED ? 0 : jn) * nx * nx;
         const MatPtr SR = M + dm.mSqR + (P::SHARED ? 0 : jn) * nu * nu;
         double tt[P::MAXNX + P::MAXNU + 2], pj[P::MAXNX + P::MAXNU + 2], lz[P::MAXNX + P::MAXNU + 2];
@@ -723,9 +730,10 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         m1 = spk_max_nan(m1, fabs(x1t));
         acc_z(dm.zt + jn, dzt, x1t);
         if (wx) m3 = spk_max_nan(m3, fabs((0.5 * lz[1 + nxu] + 0.5 * lz[0]) + x1t));
+        }
 
         // ---- leaf child: (v13; v11, v12) in SOC(nx+2), v14 in the x box (implicit_l.jl:286-317, :752-810)
-        if (s.kids_leaf) {
+        if (LEAF && s.kids_leaf) {
             const int li = j - dm.nn;
             const MatPtr SN = M + dm.mSqQN + (P::SHARED ? 0 : li) * nx * nx;
             double wl[P::MAXNX], dl[P::MAXNX];
@@ -791,13 +799,13 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         }
     }
     // xi_1 (and xi) on x_i, u_i
-    SPK_UNROLL for (int k = 0; k < nx; ++k) {
+    SPK_UNROLL for (int k = 0; k < (MAIN ? nx : 0); ++k) {
         const double x1 = ltx[k] + nig * dzx[k];
         m1 = spk_max_nan(m1, fabs(x1));
         acc_z(dm.zx + i * nx + k, dzx[k], x1);
         if (wx) m3 = spk_max_nan(m3, fabs(lxx[k] + x1));
     }
-    SPK_UNROLL for (int k = 0; k < nu; ++k) {
+    SPK_UNROLL for (int k = 0; k < (MAIN ? nu : 0); ++k) {
         const double x1 = ltu[k] + nig * dzu[k];
         m1 = spk_max_nan(m1, fabs(x1));
         acc_z(dm.zu + i * nu + k, dzu[k], x1);

@@ -43,8 +43,8 @@ SPK_DEV int group_threads_dev(int d, int stages) {   // non-leaf nodes of a comp
 
 template <class P, int MODE_, class X>
 SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
-    constexpr int MODE = (MODE_ == MODE_SUB_B_SP) ? MODE_SUB_B : (MODE_ == MODE_FULL_SP) ? MODE_FULL : MODE_;
-    constexpr bool SP_SUMS = (MODE_ != MODE);   // phase B also accumulates the SP driver's inner products
+    constexpr int MODE = (MODE_ == MODE_SUB_B_SP || MODE_ == MODE_SUB_B_LAT) ? MODE_SUB_B : (MODE_ == MODE_FULL_SP) ? MODE_FULL : MODE_;
+    constexpr bool SP_SUMS = (MODE_ == MODE_SUB_B_SP || MODE_ == MODE_FULL_SP);   // phase B also accumulates the SP driver's inner products
     const Dims &dm = a.dm;
     const P p(dm);
     const unsigned flags = a.flags;
@@ -450,9 +450,30 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
             }
             x.each([&](int tid, TState<P> &s) { x.stash3(tid, s.mx3); if (SP_SUMS) x.stash_sum3(tid, s.sp3); });
         } else if constexpr (!SP_SUMS) {
+            // Latency regime (register-resident lane-team sweep: the workgroup has T threads per node, phase B keeps only
+            // the first wave busy): the leaf-children blocks are done by thread 64 + li on the second wave while thread li
+            // does the rest of node li (b_local PART).  The leaves' x comes from the sweep's LDS vector.
+            // (A kernel of its own, MODE_SUB_B_LAT: the two extra copies of phase B change the register allocation of
+            // whatever kernel contains them -- spills in the fused SUB_BA kernel, 8 % in the batched SUB_B.)
+            constexpr bool CAN_SHADOW = (MODE_ == MODE_SUB_B_LAT) && P::REGROWS;
+            const bool leaf_shadow = CAN_SHADOW && team_reg && !crown_blk && !(bflags & F_NO_SWEEP) && nl_grp <= 64 && nthr >= 128 &&
+                                     (root_stage + stages == dm.N);
             x.each([&](int tid, TState<P> &s) {
                 double mx[3] = {0., 0., 0.};
-                if (s.active) b_local(p, dm, M, z, v, zo, vo, s, ps, bflags, mx);
+                if constexpr (CAN_SHADOW) {
+                    if (s.active) {
+                        if (leaf_shadow) b_local<P, 0, 1>(p, dm, M, z, v, zo, vo, s, ps, bflags, mx);
+                        else b_local(p, dm, M, z, v, zo, vo, s, ps, bflags, mx);
+                    } else if (leaf_shadow && tid >= 64 && tid < 64 + nl_grp) {
+                        TState<P> sh;
+                        init_geometry(p, dm, tid - 64, root_stage, root_pos, stages, crown, sh);
+                        if (sh.active && sh.kids_leaf) {
+                            for (int c = 0; c < d; ++c)
+                                for (int k = 0; k < nx; ++k) sh.xl[c][k] = tl.XL[(sh.pos * d + c) * nx + k];
+                            b_local<P, 0, 2>(p, dm, M, z, v, zo, vo, sh, ps, bflags, mx);
+                        }
+                    }
+                } else if (s.active) b_local(p, dm, M, z, v, zo, vo, s, ps, bflags, mx);
                 x.stash3(tid, mx);
             });
         } else {   // SP driver: the inner products with the residual of this evaluation ride along (b_local, SPM)

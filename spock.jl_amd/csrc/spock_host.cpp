@@ -154,7 +154,7 @@ bool team_local_applies(const Dims &dm) {
 
 LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     LaunchGeo g;
-    if (mode == MODE_SUB_B_SP) mode = MODE_SUB_B;
+    if (mode == MODE_SUB_B_SP || mode == MODE_SUB_B_LAT) mode = MODE_SUB_B;
     if (mode == MODE_FULL_SP) mode = MODE_FULL;
     const int d = dm.d, nx = dm.nx, nu = dm.nu;
     auto r64 = [](int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; };

@@ -150,7 +150,9 @@ enum SpOp { SP_FLAT1 = 1, SP_FLAT2, SP_FLAT3, SP_FLAT4, SP_FLAT5, SP_LOP_R, SP_L
 // MODE_SUB_B_SP / MODE_FULL_SP: SUB_B / FULL whose phase B also accumulates the SP driver's inner products (KArgs::sp_mode);
 // separate kernels so that the CP kernels do not carry that code and its registers
 enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, MODE_FINALIZE = 4, MODE_SUB_BA = 5,
-                 MODE_SUB_B_SP = 6, MODE_FULL_SP = 7, N_GROUP_MODES = 8 };
+                 MODE_SUB_B_SP = 6, MODE_FULL_SP = 7,
+                 MODE_SUB_B_LAT = 8,   // SUB_B of the single-instance regime: the leaf-children blocks of phase B on an idle wave
+                 N_GROUP_MODES = 9 };
 
 // ---- host build step (spock_host.cpp) -------------------------------------------------------------
 struct HostProblem {

@@ -114,7 +114,7 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     const size_t lds = g.lds_bytes;   // sized for the staged matrices either way
     const dim3 grid(g.grid_x, a.batch), block(g.threads);
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: raise it once per kernel (160 KiB per CU on MI355X)
-        static bool raised[N_GROUP_MODES] = {false, false, false, false, false, false, false, false};
+        static bool raised[N_GROUP_MODES] = {false, false, false, false, false, false, false, false, false};
         if (!raised[mode]) {
             const void *fn = mode == MODE_FULL ? (const void *)spock_group_kernel<P, MODE_FULL>
                            : mode == MODE_SUB_A ? (const void *)spock_group_kernel<P, MODE_SUB_A>
@@ -122,6 +122,7 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
                            : mode == MODE_SUB_B ? (const void *)spock_group_kernel<P, MODE_SUB_B>
                            : mode == MODE_SUB_BA ? (const void *)spock_group_kernel<P, MODE_SUB_BA>
                            : mode == MODE_SUB_B_SP ? (const void *)spock_group_kernel<P, MODE_SUB_B_SP>
+                           : mode == MODE_SUB_B_LAT ? (const void *)spock_group_kernel<P, P::REGROWS ? MODE_SUB_B_LAT : MODE_SUB_B>
                            : mode == MODE_FULL_SP ? (const void *)spock_group_kernel<P, MODE_FULL_SP>
                                                 : (const void *)spock_group_kernel<P, MODE_FINALIZE>;
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -139,6 +140,9 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
             hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_BA>), grid, block, lds, st, a);
             break;
         case MODE_SUB_B_SP: hipLaunchKernelGGL((spock_group_kernel<P, MODE_SUB_B_SP>), grid, block, lds, st, a); break;
+        case MODE_SUB_B_LAT:   // exists for the shapes with the register-resident sweep; the others run plain SUB_B
+            hipLaunchKernelGGL((spock_group_kernel<P, P::REGROWS ? MODE_SUB_B_LAT : MODE_SUB_B>), grid, block, lds, st, a);
+            break;
         case MODE_FULL_SP: hipLaunchKernelGGL((spock_group_kernel<P, MODE_FULL_SP>), grid, block, lds, st, a); break;
         default: return (int)hipErrorInvalidValue;
     }

@@ -94,6 +94,7 @@ static int launch_variant(int mode, const KArgs &a_in) {
         case MODE_FINALIZE: run_blocks<P, MODE_FINALIZE>(a, gx, thr); break;
         case MODE_SUB_BA: run_blocks<P, MODE_SUB_BA>(a, gx, thr); break;
         case MODE_SUB_B_SP: run_blocks<P, MODE_SUB_B_SP>(a, gx, thr); break;
+        case MODE_SUB_B_LAT: run_blocks<P, P::REGROWS ? MODE_SUB_B_LAT : MODE_SUB_B>(a, gx, thr); break;
         case MODE_FULL_SP: run_blocks<P, MODE_FULL_SP>(a, gx, thr); break;
         default: return 1;
     }
