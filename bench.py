@@ -1,30 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X Chambolle-Pock hot path.
+"""bench.py -- headline benchmark of the MI355X Chambolle-Pock / Spock hot path.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json config 2): server_heat tree, nx=5, nu=2, branching 2, 4096 leaves (reference N=13),
-fp64, synthetic deterministic data.  Every rank holds `--batch` independent problem instances (own x0, own
-state); a STEP is `--iters` Chambolle-Pock iterations (one evaluation of T = (prox_f, prox_h*) + L, L' + the
-termination residuals each) of every instance, run as ONE solve call with tol = 0 so that no instance stops
-early: the work per step is fixed.  All inputs are resident in HBM before the timed region (a step uploads
-only the nx-double x0 per instance and reads back one 120-byte control block per instance).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run ...`; the parent never touches a GPU) and passes rank 0's JSON line through.
 
-value = n_gpus * batch * iters * steps / time  ("Spock iterations per second", whole job).
+Workload of `value` (BASELINE.json config 2): server_heat tree, nx=5, nu=2, branching 2, 4096 leaves (reference N=13),
+fp64, synthetic deterministic data.  Every rank holds `--batch` independent problem instances (own x0, own state); a STEP
+is `--iters` Chambolle-Pock iterations (one evaluation of T = (prox_f, prox_h*) + L, L' + the termination residuals each)
+of every instance, run as ONE solve call with tol = 0 so that no instance stops early: the work per step is fixed.  All
+inputs are resident in HBM before the timed region (a step uploads only the nx-double x0 per instance and reads back one
+120-byte control block per instance).
+
+    value = n_gpus * batch * iters * steps / time      ("Spock iterations per second", whole job, weak scaling)
 
 The JSON line also carries
-  roofline      the dominant kernel (subtree phase-B kernel): algorithmic bytes per launch / its average HIP-event
-                duration, measured live after the timed region on the stream the kernels run on
-  cpu_baseline  the CPU oracle (single-thread C restatement of the reference) on ONE instance of the same
-                workload, on this box's host cores (rank 0, N=1 only)
-  single_instance  latency-bound regime: iterations/s of ONE instance and ms-to-tol (tol 1e-3, SILENT rule) of
-                the reference-faithful nu=5 variant of the same tree, next to the oracle's time for the same solve
+  roofline        the dominant kernel: algorithmic bytes per launch / its average HIP-event duration,
+                  measured live after the timed region on the stream the kernels run on; `necessary_bytes_per_launch` is
+                  the entry-by-entry count of what that kernel must move, `frac_necessary` the fraction of the HBM peak on it;
+                  `traffic` = PMC bytes of the same kernel from the committed rocprofv3 pass of the SAME library build
+                  (null when the pass is of another build)
+  cpu_baseline    the CPU oracle (single-thread C restatement of the reference) on ONE instance of the same workload, on
+                  this box's host cores (rank 0, N=1 only), plus the same with one oracle process per host core
+  single_instance latency-bound regime (N=1 only)
+  mpc_cfg4        BASELINE config 4, the metric's "1/2/4/8-GPU problems/sec": closed-loop simulations of
+                  examples/server_heat/mpc_simulation.jl (nx = nu = 20, N = 10, SP, 20 warm-started steps each, tol 1e-3)
+                  sharded over the ranks through dist.mpc_simulation_sharded -- weak (8 simulations per GPU) and strong
+                  (64 in total); problems = closed-loop simulations, solves = simulations x 20
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,11 +44,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec), ~6.3 TB/s achievable
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="problem instances per GPU (4.4 MB of state each)")
+    ap.add_argument("--iters", type=int, default=96, help="CP iterations per step (rounded up to a multiple of 6)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--no-mpc", action="store_true")
+    ap.add_argument("--mpc-per-gpu", type=int, default=8)
+    ap.add_argument("--mpc-total", type=int, default=64)
+    # test hooks (tests/test_bench_contract.py drives the whole N = 2 path on CPUs with the emulation library)
+    ap.add_argument("--tree-N", type=int, default=13, help=argparse.SUPPRESS)
+    ap.add_argument("--mpc-N", type=int, default=10, help=argparse.SUPPRESS)
+    ap.add_argument("--mpc-nx", type=int, default=20, help=argparse.SUPPRESS)
+    ap.add_argument("--mpc-steps", type=int, default=20, help=argparse.SUPPRESS)
+    ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def launch_command(args, argv, port):
+    """The command the parent runs for `--gpus N` (N > 1): one process per GPU under torch.distributed.run."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def algorithmic_bytes(flat):
@@ -49,36 +91,74 @@ def algorithmic_bytes(flat):
     return {"sub_a": phase_a, "sub_b": phase_b, "cp_iteration": phase_a + phase_b}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="problem instances per GPU (4.4 MB of state each)")
-    ap.add_argument("--iters", type=int, default=100, help="CP iterations per step (even)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single", action="store_true")
-    args = ap.parse_args()
+def necessary_bytes(flat):
+    """What the fused iteration kernel must move per instance and CP iteration, entry by entry (W = 8): it reads the iterate
+    (z, v), the s / tau / y part of zbar that the previous launch's phase A produced, and d; it writes zbar, vbar and d.
+    (The termination test re-reads nothing, q never leaves LDS / registers, zbar's x / u go from the sweep to phase B in
+    registers.)  Smaller than SURVEY 8d's model, which counts an unfused implementation's streams."""
+    W = 8
+    szy = flat.n + (flat.n - 1) + flat.nn * flat.ny
+    d = flat.nn * flat.nu
+    return W * ((flat.nz + flat.nv + szy + d) + (flat.nz + flat.nv + d))
+
+
+def lib_fingerprint(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def disturbances(lo, hi, steps, d):
+    import numpy as np
+    # the reference draws rand(1:d) (mpc_simulation.jl:170); here numpy PCG64 seeded with the simulation index
+    return np.stack([np.random.default_rng(seed).integers(0, d, size=steps) for seed in range(lo, hi)]).astype(np.int32) \
+        if hi > lo else np.zeros((0, steps), dtype=np.int32)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the ranks as a CHILD process: this parent has not initialised a GPU and never will
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        proc = subprocess.run(launch_command(args, argv, free_port()), env=env)
+        return proc.returncode
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    on_gpu = args.backend == "nccl"
+    if on_gpu and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     n_gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    tdev = torch.device("cuda", local_rank) if on_gpu else None
+    dev_index = local_rank if on_gpu else 0
 
     import spock_jl_amd as S
     from spock_jl_amd import dist as sdist
+    from spock_jl_amd import _lib as slib
 
-    N_REF, NX, NU, D = 13, 5, 2, 2
-    B, M = args.batch, args.iters + (args.iters & 1)
+    lib_kw = {"lib_path": args.lib} if args.lib else {}
+    N_REF, NX, NU, D = args.tree_N, 5, 2, 2
+    B, M = args.batch, ((args.iters + 5) // 6) * 6
     specs = S.get_server_heat_specs(N_REF, NX, D, nu=NU)
     flat = S.flatten_problem(*specs)
-    model = S.build_model(*specs, S.SolverOptions(S.CP, None), batch=B, device=local_rank, max_iter=M, graph_iters=M)
+    model = S.build_model(*specs, S.SolverOptions(S.CP, None), batch=B, device=dev_index, max_iter=M, graph_iters=M, **lib_kw)
     inst0 = rank * B
     x0 = 0.1 * (1.0 + 0.001 * (inst0 + np.arange(B)))[:, None] * np.ones((B, NX))
 
@@ -88,7 +168,15 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -97,60 +185,94 @@ def main():
     for _ in range(args.steps):
         res = step()
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     res = res if isinstance(res, list) else [res]
     assert all(r["iterations"] == M for r in res), "a step must run exactly --iters iterations"
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # the path's only collective: the trivial result gather (nu + 5 doubles per instance)
-        rec = sdist.gather_records(sdist.instance_record(model, res, NU), [B] * world, device=torch.device("cuda", local_rank))
+        rec = sdist.gather_records(sdist.instance_record(model, res, NU), [B] * world, device=tdev)
         assert rec.shape == (B * world, NU + 5)
     value = n_gpus * B * M * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: HIP events around every launch, same workload, same stream
-    bytes_ = algorithmic_bytes(flat)
-    prof = model.profile_kernels(40)
-    split = model.sizes.split_stage > 0
-    dom = max(("sub_a", "crown", "sub_b", "full"), key=lambda k: prof[k][0] * (prof[k][1] > 0))
-    dom_ms = prof[dom][0]
+    roofline = None
     fused = bool(model.sizes.fused_iteration)
-    if fused:   # "sub_b" is then the fused SUB_BA kernel: phase B of iteration k + phase A / backward sweep of k + 1 = one whole iteration
-        bytes_["sub_b"] = bytes_["cp_iteration"]
-    dom_bytes = B * (bytes_[dom] if dom in bytes_ else bytes_["cp_iteration"])
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    # measured HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come
-    # from the committed rocprofv3 --pmc passes of this same command (profiles/<round>/pmc_b<batch>_summary.json,
-    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), null when no pass exists for this batch size
-    traffic = None
-    for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        f = os.path.join(ROOT, "profiles", rnd, f"pmc_b{B}_summary.json")
-        if os.path.exists(f):
-            k = json.load(open(f)).get("kernels", {}).get("sub_ba" if (fused and dom == "sub_b") else dom)
-            if k:
-                traffic = k["hbm_bytes_per_launch_corrected"]
-            break
-    roofline = {"bound": "hbm", "kernel": {"sub_a": "spock_group_kernel<MODE_SUB_A>", "sub_b": "spock_group_kernel<MODE_SUB_BA>" if fused else "spock_group_kernel<MODE_SUB_B>",
-                                             "crown": "spock_group_kernel<MODE_CROWN>", "full": "spock_group_kernel<MODE_FULL>"}[dom],
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
-                "launches_timed": prof[dom][1],
-                "all_kernels_avg_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1]},
-                "whole_iteration_frac": round(B * bytes_["cp_iteration"] * n_gpus / (elapsed / (M * args.steps)) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4)}
+    if on_gpu:
+        bytes_ = algorithmic_bytes(flat)
+        prof = model.profile_kernels(36)
+        dom = max(("sub_a", "crown", "sub_b", "full"), key=lambda k: prof[k][0] * (prof[k][1] > 0))
+        dom_ms = prof[dom][0]
+        if fused:   # "sub_b" is then the fused kernel: phase B of iteration k + phase A / backward sweep of k + 1 = one whole iteration
+            bytes_["sub_b"] = bytes_["cp_iteration"]
+        dom_bytes = B * (bytes_[dom] if dom in bytes_ else bytes_["cp_iteration"])
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        nec = B * necessary_bytes(flat) if (fused and dom == "sub_b") else None
+        # measured HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from the
+        # committed rocprofv3 --pmc passes of this same command (profiles/<round>/pmc_b<batch>_summary.json, FETCH_SIZE doubled
+        # as MI355X_MICROARCH.md prescribes for gfx950) -- taken only when that pass ran the SAME library build as this run
+        traffic = traffic_raw = None
+        fp = lib_fingerprint(args.lib or slib.DEFAULT_LIB)
+        pdir = os.path.join(ROOT, "profiles")
+        for rnd in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+            f = os.path.join(pdir, rnd, f"pmc_b{B}_summary.json")
+            if os.path.exists(f):
+                summ = json.load(open(f))
+                k = summ.get("kernels", {}).get("sub_ba" if (fused and dom == "sub_b") else dom)
+                if k and summ.get("lib_sha16") == fp:
+                    traffic = k["hbm_bytes_per_launch_corrected"]; traffic_raw = k.get("hbm_bytes_per_launch_raw")
+                break
+        kname = {"sub_a": "SUB_A", "sub_b": "SUB_BA" if fused else "SUB_B", "crown": "CROWN", "full": "FULL"}[dom]
+        roofline = {"bound": "hbm", "kernel": f"spock {'interleaved ' if getattr(model.sizes, 'interleaved', 0) else ''}group kernel, mode {kname}",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_raw": traffic_raw, "algorithmic_bytes_per_launch": dom_bytes,
+                    "necessary_bytes_per_launch": nec,
+                    "frac_necessary": round(nec / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if nec else None,
+                    "frac_measured": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "avg_launch_ms": round(dom_ms, 5), "launches_timed": prof[dom][1], "lib_sha16": fp,
+                    "all_kernels_avg_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1]},
+                    "whole_iteration_frac": round(B * bytes_["cp_iteration"] * n_gpus / (elapsed / (M * args.steps)) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4)}
     model.close()
 
     out = {"metric": "Spock (Chambolle-Pock) iterations/sec on the server_heat tree", "value": round(value, 1),
            "unit": "iterations/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "server_heat nx=5 nu=2 d=2, 4096 leaves (reference N=13), CP iteration incl. termination residuals",
+           "config": {"workload": f"server_heat nx=5 nu=2 d=2, {flat.nl} leaves (reference N={N_REF}), CP iteration incl. termination residuals",
                       "instances_per_gpu": B, "iterations_per_step": M, "nz": flat.nz, "nv": flat.nv,
                       "split_stage": int(model.sizes.split_stage), "algorithm": "CP", "fused_iteration": fused,
                       "parallelism": f"{n_gpus} x {B} independent instances, RCCL all_gather of results only"},
            "roofline": roofline}
 
-    if rank == 0 and world == 1:
+    # ---- BASELINE config 4: closed-loop MPC simulations sharded over the ranks (the metric's problems/sec leg)
+    if not args.no_mpc:
+        mspecs = S.get_server_heat_specs(args.mpc_N, args.mpc_nx, 2)
+        steps = args.mpc_steps
+        legs = {}
+        for name, total in (("weak", args.mpc_per_gpu * world), ("strong", args.mpc_total)):
+            lo, hi = sdist.shard_range(total, world, rank)
+            xa = 0.1 * (1.0 + 0.01 * np.arange(total))[:, None] * np.ones((total, args.mpc_nx))
+            wa = disturbances(0, total, steps, 2)
+            mm = S.build_model(*mspecs, S.SolverOptions(S.SP, None), batch=max(hi - lo, 1), device=dev_index, **lib_kw) if hi > lo else None
+            if mm is not None:   # warm-up run (code upload, graph capture), then back to the freshly built model
+                S.mpc_simulation(mm, xa[lo:hi], wa[lo:hi], tol=1e-3); mm.reset()
+            fence()
+            t = time.perf_counter()
+            recs, _, _ = sdist.mpc_simulation_sharded(mspecs, xa, wa, tol=1e-3, model=mm, torch_device=tdev)
+            fence()
+            dt = max_over_ranks(time.perf_counter() - t)
+            if mm is not None:
+                mm.close()
+            assert recs.shape == (total, args.mpc_nx + 5)
+            legs[name] = {"simulations": total, "per_gpu": [sdist.shard_range(total, world, r)[1] - sdist.shard_range(total, world, r)[0] for r in range(world)],
+                          "steps_per_simulation": steps, "ms": round(dt * 1e3, 2),
+                          "problems_per_s": round(total / dt, 2), "solves_per_s": round(total * steps / dt, 1),
+                          "sp_iterations_total": int(recs[:, args.mpc_nx].sum()), "all_converged": bool((recs[:, args.mpc_nx + 1] == 0).all()),
+                          "max_final_state": float(recs[:, args.mpc_nx + 2].max())}
+        out["mpc_cfg4"] = dict(legs, workload=f"mpc_simulation.jl: server_heat nx=nu={args.mpc_nx}, d=2, N={args.mpc_N}, SP, tol 1e-3, "
+                                              f"{steps} warm-started steps per simulation; one all_gather of (nu+5) doubles per simulation",
+                               unit="closed-loop simulations/s")
+
+    if rank == 0 and world == 1 and on_gpu:
         from oracle import oracle as O
         if not args.no_cpu_baseline:
             # bounded CPU sample of the same workload: ONE instance, as many CP iterations as fit ~12 s
@@ -162,9 +284,20 @@ def main():
                                    "host_cores_available": os.cpu_count(),
                                    "sample": f"{k} CP iterations of one instance of the same workload, single-thread C oracle "
                                              f"(the reference is Julia; no Julia toolchain exists on this box)"}
+            # the same with every host core busy: one independent oracle process per core (instances are independent)
+            ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            kk = max(20, k // 4)
+            code = ("import sys,time,numpy as np;sys.path.insert(0,%r);import spock_jl_amd as S;from oracle import oracle as O;"
+                    "f=S.flatten_problem(*S.get_server_heat_specs(%d,5,2,nu=2));o=O.Oracle(f,O.CP);o.solve(np.full(5,.1),tol=0.,max_iter=5);"
+                    "t=time.perf_counter();o.solve(np.full(5,.1),tol=0.,max_iter=%d);print(time.perf_counter()-t)" % (ROOT, N_REF, kk))
+            t = time.perf_counter()
+            procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE) for _ in range(ncore)]
+            times = [float(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
+            out["cpu_baseline"]["all_cores"] = {"cores": ncore, "value": round(ncore * kk / max(times), 1), "unit": "iterations/s",
+                                                "sample": f"{ncore} independent oracle processes x {kk} CP iterations, slowest process timed"}
         if not args.no_single:
             single = {}
-            m1 = S.build_model(*specs, S.SolverOptions(S.CP, None), batch=1, device=local_rank, max_iter=2000, graph_iters=100)
+            m1 = S.build_model(*specs, S.SolverOptions(S.CP, None), batch=1, device=dev_index, max_iter=2000, graph_iters=100)
             S.solve_model(m1, x0[:1], tol=0.0)
             torch.cuda.synchronize(); t = time.perf_counter(); r = S.solve_model(m1, x0[:1], tol=0.0); dt = time.perf_counter() - t
             single["iterations_per_s"] = round(r["iterations"] / dt, 1)
@@ -172,14 +305,14 @@ def main():
             m1.close()
             specs5 = S.get_server_heat_specs(N_REF, NX, D)           # reference-faithful nu = nx = 5: converges
             flat5 = S.flatten_problem(*specs5)
-            m5 = S.build_model(*specs5, S.SolverOptions(S.CP, None), batch=1, device=local_rank)
+            m5 = S.build_model(*specs5, S.SolverOptions(S.CP, None), batch=1, device=dev_index)
             S.solve_model(m5, np.full(NX, 0.1), tol=1e-3); m5.reset()
             r5 = S.solve_model(m5, np.full(NX, 0.1), tol=1e-3)
             single["ms_to_tol_1e-3_nu5"] = round(r5["solve_ms"], 3)
             single["iterations_to_tol_nu5"] = r5["iterations"]
             m5.close()
             # the Spock algorithm proper (SuperMann-accelerated CP, SolverOptions(SP, nothing)) on the same convergent tree
-            ms = S.build_model(*specs5, S.SolverOptions(S.SP, None), batch=1, device=local_rank)
+            ms = S.build_model(*specs5, S.SolverOptions(S.SP, None), batch=1, device=dev_index)
             S.solve_model(ms, np.full(NX, 0.1), tol=1e-3); ms.reset()
             rs = S.solve_model(ms, np.full(NX, 0.1), tol=1e-3)
             single["sp_ms_to_tol_1e-3_nu5"] = round(rs["solve_ms"], 3)
@@ -200,7 +333,7 @@ def main():
             probs = {}
             X = 0.1 * (1.0 + 0.01 * np.arange(64))[:, None] * np.ones((64, NX))
             for name, alg in (("cp", S.CP), ("sp", S.SP)):
-                mb = S.build_model(*specs5, S.SolverOptions(alg, None), batch=64, device=local_rank)
+                mb = S.build_model(*specs5, S.SolverOptions(alg, None), batch=64, device=dev_index)
                 S.solve_model(mb, X, tol=1e-3); mb.reset()
                 torch.cuda.synchronize(); t = time.perf_counter(); rb = S.solve_model(mb, X, tol=1e-3); torch.cuda.synchronize()
                 dtb = time.perf_counter() - t
@@ -215,7 +348,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -63,6 +63,18 @@ namespace {
         if (_e != 0) return fail(SPOCK_ERR_HIP, std::string(#expr) + ": " + rt::err(_e));      \
     } while (0)
 
+// Every ABI entry point runs with the handle's device current and puts the caller's current device back on return
+// (a process may hold handles on several GPUs, or use another device through torch).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (rt::get_device(&prev) != 0) prev = -1;
+        if (prev != dev) changed = (rt::set_device(dev) == 0);
+    }
+    ~DeviceGuard() { if (changed && prev >= 0) rt::set_device(prev); }
+};
+
 template <class T>
 int dev_alloc(spock_handle_s *h, T **p, size_t count) {
     void *q = nullptr;
@@ -151,12 +163,23 @@ Ctl fresh_ctl(const spock_handle_s *h, double gamma, double sigma, double tol, i
 }
 
 // Fused or three-kernel sequence?  The fused kernel saves a launch and the re-read of zbar / vbar, but it is the most
-// register-hungry kernel of the library: for some shapes (nx = nu = 5) the compiler spills in it and the plain sequence
-// is faster.  Decided once per handle by timing a few iterations of both on the zero state, with the handle's own
-// batch size (SPOCK_AMD_FUSE=1 / 0 forces the choice).  The iterates of the two sequences agree to rounding.
+// register-hungry kernel of the library: for the larger shapes (nx = nu = 5 and up) the compiler spills in it and the plain
+// sequence is faster.  The choice is a deterministic rule on the shape (measured on MI355X: (nx, nu) = (5, 2) fused wins at
+// batch 1 and 1024, (5, 5) / (20, 20) / (64, 16) the plain sequence wins), so that two handles of the same problem always
+// run the same kernels and give bitwise identical iterates; spock_sizes_t.fused_iteration reports it.
+// SPOCK_AMD_FUSE=1 / 0 forces the choice, SPOCK_AMD_FUSE=time decides by timing six iterations of both (experiments).
+int time_cp_sequences(spock_handle_s *h);
 int choose_cp_sequence(spock_handle_s *h) {
-    if (const char *e = std::getenv("SPOCK_AMD_FUSE")) { h->fused = (e[0] == '1'); return 0; }
+    const Dims &dm = h->bp.dm;
+    h->fused = dm.t0 > 0 && (dm.nx + dm.nu <= 8);
     if (std::getenv("SPOCK_AMD_NO_FUSE")) { h->fused = false; return 0; }
+    if (const char *e = std::getenv("SPOCK_AMD_FUSE")) {
+        if (e[0] == 't') return time_cp_sequences(h);
+        h->fused = dm.t0 > 0 && (e[0] == '1');
+    }
+    return 0;
+}
+int time_cp_sequences(spock_handle_s *h) {
     if (!rt::timing_supported()) return 0;
     const size_t B = (size_t)h->batch;
     const Dims &dm = h->bp.dm;
@@ -192,6 +215,7 @@ int choose_cp_sequence(spock_handle_s *h) {
 int run_op(spock_handle_s *h, const double *z_in, const double *v_in, const double *zbar_in, const double *x0,
            double gamma, double sigma, unsigned flags, bool phase_a, bool phase_b, double *z_out, double *v_out) {
     const Dims &dm = h->bp.dm;
+    DeviceGuard guard(h->device);
     RTCHECK(ensure_op_buffers(h));
     const size_t bz = sizeof(double) * dm.nz, bv = sizeof(double) * dm.nv;
     if (z_in) RTCHECK(rt::h2d(h->o_z[0], z_in, bz, h->stream)); else RTCHECK(rt::dzero(h->o_z[0], bz, h->stream));
@@ -401,8 +425,14 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     int gi = o ? o->graph_iters : 0;
     if (const char *e = std::getenv("SPOCK_AMD_GRAPH_ITERS")) gi = std::atoi(e);
     if (gi == 0) gi = (alg == SPOCK_ALG_SP) ? 8 : 32;
-    if (gi > 0 && alg == SPOCK_ALG_CP) gi = ((gi + 5) / 6) * 6;   // a multiple of 6 brings the buffer rotation back to slot 0
-    else if (gi > 0 && (gi & 1)) gi += 1;
+    {   // negative = eager launches of |gi| iterations per poll.  Either way every repetition starts at buffer slot 0, so
+        // |gi| is a multiple of 6 for CP (z rotates through three buffers, v through two) and even for SP
+        const int sgn = gi < 0 ? -1 : 1;
+        int mag = gi < 0 ? -gi : gi;
+        if (alg == SPOCK_ALG_CP) mag = ((mag + 5) / 6) * 6;
+        else if (mag & 1) mag += 1;
+        gi = sgn * mag;
+    }
     h->graph_iters = gi;
     int split = o ? o->split_stage : 0;
     if (const char *e = std::getenv("SPOCK_AMD_SPLIT_STAGE")) split = std::atoi(e);
@@ -418,8 +448,9 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         spock_destroy(h);
         return fail(SPOCK_ERR_HIP, m);
     };
-    int e = rt::set_device(h->device);
-    if (e) return bail(e, "hipSetDevice");
+    DeviceGuard guard(h->device);
+    int e = 0;
+    { int cur = -1; if ((e = rt::get_device(&cur)) || cur != h->device) return bail(e ? e : 101 /* hipErrorInvalidDevice */, "hipSetDevice"); }
     if ((e = rt::stream_create(&h->stream))) return bail(e, "hipStreamCreate");
     if ((e = rt::event_create(&h->ev0)) || (e = rt::event_create(&h->ev1))) return bail(e, "hipEventCreate");
     const size_t B = (size_t)h->batch;
@@ -429,8 +460,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         for (int k = 0; k < 3; ++k) if ((e = dev_alloc(h, &h->d_z[k], B * dm.nz))) return bail(e, "hipMalloc(state)");
         for (int k = 0; k < 2; ++k) if ((e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
         if ((e = dev_alloc(h, &h->d_v2x, B * (size_t)dm.nsub))) return bail(e, "hipMalloc(state)");
-        h->fused = dm.t0 > 0;
-        h->lat_regime = dm.t0 > 0 && launch_geometry(MODE_SUB_B, dm, h->batch).team_reg != 0;
+            h->lat_regime = dm.t0 > 0 && launch_geometry(MODE_SUB_B, dm, h->batch).team_reg != 0;
     } else {
         const size_t nr = (size_t)dm.nz + dm.nv;
         for (int k = 0; k < 10; ++k) if ((e = dev_alloc(h, &h->s_vec[k], B * nr))) return bail(e, "hipMalloc(SP state)");
@@ -456,7 +486,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     h->h_ctl.assign(B, fresh_ctl(h, 0., 0., 0., SPOCK_SILENT));
     for (auto &c : h->h_ctl) c.done = 1;
     if ((e = rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream))) return bail(e, "upload");
-    if (alg == SPOCK_ALG_CP && h->fused && (e = choose_cp_sequence(h))) return bail(e, "timing the CP kernel sequences");
+    if (alg == SPOCK_ALG_CP && (e = choose_cp_sequence(h))) return bail(e, "timing the CP kernel sequences");
     if (alg == SPOCK_ALG_SP) h->sp_fused = !std::getenv("SPOCK_AMD_SP_LOP");
     if (alg == SPOCK_ALG_SP && (e = sp_init_state(h))) return bail(e, "SP state initialisation");
     if ((e = rt::sync(h->stream))) return bail(e, "hipStreamSynchronize");
@@ -466,6 +496,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
 
 int spock_destroy(spock_handle_t h) {
     if (!h) return SPOCK_OK;
+    DeviceGuard guard(h->device);
     if (h->stream) rt::sync(h->stream);
     if (h->graph) rt::graph_destroy(h->graph);
     for (void *p : h->allocs) rt::dfree(p);
@@ -494,6 +525,7 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
 int spock_solve(spock_handle_t h, const double *x0, double tol, int32_t verbose, const double *z0, const double *v0,
                 double gamma, double sigma, spock_result_t *results) {
     if (!h || !x0) return fail(SPOCK_ERR_BAD_ARG, "handle and x0 must not be NULL");
+    DeviceGuard guard(h->device);
     return solve_impl(h, x0, tol, verbose, z0, v0, gamma, sigma, results);
 }
 
@@ -503,6 +535,7 @@ int spock_solve(spock_handle_t h, const double *x0, double tol, int32_t verbose,
 int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const int32_t *w_seq, double tol, int32_t verbose,
                        double *x_traj, double *u_traj, spock_result_t *results) {
     if (!h || !x0 || !w_seq || steps < 1) return fail(SPOCK_ERR_BAD_ARG, "handle, x0, w_seq must not be NULL and steps >= 1");
+    DeviceGuard guard(h->device);
     const Dims &dm = h->bp.dm;
     const size_t B = (size_t)h->batch;
     for (size_t k = 0; k < B * (size_t)steps; ++k)
@@ -510,11 +543,14 @@ int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const 
     int *d_w = nullptr;
     double *d_xt = nullptr, *d_ut = nullptr;
     void *pw = nullptr, *pxt = nullptr, *put = nullptr;
-    RTCHECK(rt::dmalloc(&pw, B * steps * sizeof(int)));
-    RTCHECK(rt::dmalloc(&pxt, B * (steps + 1) * dm.nx * sizeof(double)));
-    RTCHECK(rt::dmalloc(&put, B * steps * dm.nu * sizeof(double)));
+    auto cleanup = [&]() { if (pw) rt::dfree(pw); if (pxt) rt::dfree(pxt); if (put) rt::dfree(put); };
+    {
+        int e = rt::dmalloc(&pw, B * steps * sizeof(int));
+        if (!e) e = rt::dmalloc(&pxt, B * (steps + 1) * dm.nx * sizeof(double));
+        if (!e) e = rt::dmalloc(&put, B * steps * dm.nu * sizeof(double));
+        if (e) { cleanup(); return fail(SPOCK_ERR_HIP, std::string("hipMalloc(trajectories): ") + rt::err(e)); }
+    }
     d_w = (int *)pw; d_xt = (double *)pxt; d_ut = (double *)put;
-    auto cleanup = [&]() { rt::dfree(pw); rt::dfree(pxt); rt::dfree(put); };
     int rc = SPOCK_OK;
     do {
         int e = rt::h2d(d_w, w_seq, B * steps * sizeof(int), h->stream);
@@ -596,10 +632,17 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
     if (!all_done) return fail(SPOCK_ERR_HIP, "driver did not terminate (internal error)");
     // the persistent state of every instance lives in buffer 0 between solves
     int evals = 0;
+    bool same_parity = true;   // every instance stopped at the same iteration (always with tol = 0): one copy per array
+    for (size_t b = 1; b < B; ++b) same_parity = same_parity && h->h_ctl[b].result_parity == h->h_ctl[0].result_parity;
+    if (same_parity) {
+        const int rp = h->h_ctl[0].result_parity;
+        if (rp % 3) RTCHECK(rt::d2d(h->d_z[0], h->d_z[rp % 3], B * dm.nz * sizeof(double), h->stream));
+        if (rp % 2) RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * dm.nv * sizeof(double), h->stream));
+    }
     for (size_t b = 0; b < B; ++b) {
         const Ctl &c = h->h_ctl[b];
-        if (c.result_parity % 3) RTCHECK(rt::d2d(h->d_z[0] + b * dm.nz, h->d_z[c.result_parity % 3] + b * dm.nz, sizeof(double) * dm.nz, h->stream));
-        if (c.result_parity % 2) RTCHECK(rt::d2d(h->d_v[0] + b * dm.nv, h->d_v[1] + b * dm.nv, sizeof(double) * dm.nv, h->stream));
+        if (!same_parity && c.result_parity % 3) RTCHECK(rt::d2d(h->d_z[0] + b * dm.nz, h->d_z[c.result_parity % 3] + b * dm.nz, sizeof(double) * dm.nz, h->stream));
+        if (!same_parity && c.result_parity % 2) RTCHECK(rt::d2d(h->d_v[0] + b * dm.nv, h->d_v[1] + b * dm.nv, sizeof(double) * dm.nv, h->stream));
         if (c.evals > evals) evals = c.evals;
         if (results) {
             spock_result_t &r = results[b];
@@ -615,6 +658,7 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
 
 int spock_get_z(spock_handle_t h, double *z_out) {
     if (!h || !z_out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    DeviceGuard guard(h->device);
     if (h->alg == SPOCK_ALG_SP) {
         const size_t nr = (size_t)h->bp.dm.nz + h->bp.dm.nv;
         for (int b = 0; b < h->batch; ++b)
@@ -628,6 +672,7 @@ int spock_get_z(spock_handle_t h, double *z_out) {
 }
 int spock_get_v(spock_handle_t h, double *v_out) {
     if (!h || !v_out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    DeviceGuard guard(h->device);
     if (h->alg == SPOCK_ALG_SP) {
         const size_t nr = (size_t)h->bp.dm.nz + h->bp.dm.nv;
         for (int b = 0; b < h->batch; ++b)
@@ -641,6 +686,7 @@ int spock_get_v(spock_handle_t h, double *v_out) {
 }
 int spock_set_state(spock_handle_t h, const double *z, const double *v) {
     if (!h || !z || !v) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    DeviceGuard guard(h->device);
     if (h->alg == SPOCK_ALG_SP) {
         const size_t nr = (size_t)h->bp.dm.nz + h->bp.dm.nv;
         for (int b = 0; b < h->batch; ++b) {
@@ -657,6 +703,7 @@ int spock_set_state(spock_handle_t h, const double *z, const double *v) {
 }
 int spock_reset(spock_handle_t h) {
     if (!h) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    DeviceGuard guard(h->device);
     if (h->alg == SPOCK_ALG_SP) { RTCHECK(sp_init_state(h)); return SPOCK_OK; }
     for (int k = 0; k < 3; ++k) RTCHECK(rt::dzero(h->d_z[k], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
     for (int k = 0; k < 2; ++k) RTCHECK(rt::dzero(h->d_v[k], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
@@ -666,6 +713,7 @@ int spock_reset(spock_handle_t h) {
 
 int spock_get_history(spock_handle_t h, int32_t inst, double *xi, double *xi1, double *xi2, int32_t *backtrack, int32_t cap, int32_t *len) {
     if (!h || inst < 0 || inst >= h->batch) return fail(SPOCK_ERR_BAD_ARG, "bad instance");
+    DeviceGuard guard(h->device);
     const int cnt = h->h_ctl[inst].evals < h->hist_cap ? h->h_ctl[inst].evals : h->hist_cap;
     if (len) *len = cnt;
     const int k = cnt < cap ? cnt : cap;
@@ -746,6 +794,7 @@ int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_
 int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_t *launches) {
     if (!h || !avg_ms || reps < 1) return fail(SPOCK_ERR_BAD_ARG, "bad argument");
     if (h->alg != SPOCK_ALG_CP) return fail(SPOCK_ERR_UNSUPPORTED, "kernel profiling is implemented for CP handles");
+    DeviceGuard guard(h->device);
     // `reps` further CP iterations on the current state, launched one kernel at a time with a HIP event before
     // and after each launch on the handle's stream; per kind: 0 SUB_A, 1 CROWN, 2 SUB_B or the fused SUB_BA, 3 FULL.
     // (With the fused sequence SUB_A runs once, ahead of the first iteration.)
@@ -797,6 +846,7 @@ int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_
 
 int spock_debug_stamps(spock_handle_t h, uint64_t *out /* [3][64][2] */) {
     if (!h || !out) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    DeviceGuard guard(h->device);
     RTCHECK(rt::d2h(out, h->d_dbg, sizeof(uint64_t) * 3 * 64 * 2, h->stream));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;

@@ -114,8 +114,12 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     const size_t lds = g.lds_bytes;   // sized for the staged matrices either way
     const dim3 grid(g.grid_x, a.batch), block(g.threads);
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: raise it once per kernel (160 KiB per CU on MI355X)
-        static bool raised[N_GROUP_MODES] = {false, false, false, false, false, false, false, false, false};
-        if (!raised[mode]) {
+        static bool raised_dev[16][N_GROUP_MODES] = {};   // the attribute is per device (and per kernel = per template instance)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+        bool always = false;
+        bool &raised_flag = dev >= 0 ? raised_dev[dev][mode] : always;
+        if (!raised_flag) {
             const void *fn = mode == MODE_FULL ? (const void *)spock_group_kernel<P, MODE_FULL>
                            : mode == MODE_SUB_A ? (const void *)spock_group_kernel<P, MODE_SUB_A>
                            : mode == MODE_CROWN ? (const void *)spock_group_kernel<P, MODE_CROWN>
@@ -127,7 +131,7 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
                                                 : (const void *)spock_group_kernel<P, MODE_FINALIZE>;
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
-            raised[mode] = true;
+            raised_flag = true;
         }
     }
     switch (mode) {

@@ -7,6 +7,7 @@
 namespace spock {
 namespace rt {
 int set_device(int dev);
+int get_device(int *dev);
 int stream_create(void **s);
 int stream_destroy(void *s);
 int dmalloc(void **p, size_t bytes);

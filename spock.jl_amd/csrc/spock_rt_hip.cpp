@@ -7,6 +7,7 @@ namespace spock {
 namespace rt {
 #define RT(x) return (int)(x)
 int set_device(int dev) { RT(hipSetDevice(dev)); }
+int get_device(int *dev) { RT(hipGetDevice(dev)); }
 int stream_create(void **s) { hipStream_t st; hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking); *s = (void *)st; RT(e); }
 int stream_destroy(void *s) { RT(hipStreamDestroy((hipStream_t)s)); }
 int dmalloc(void **p, size_t bytes) { RT(hipMalloc(p, bytes ? bytes : 8)); }

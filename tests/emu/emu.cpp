@@ -256,6 +256,7 @@ int launch_mpc_advance(const MpcArgs &a, void *) {
 // ---- spock_rt.hpp on host memory ---------------------------------------------------------------------
 namespace rt {
 int set_device(int) { return 0; }
+int get_device(int *d) { *d = 0; return 0; }
 int stream_create(void **s) { *s = (void *)0x1; return 0; }
 int stream_destroy(void *) { return 0; }
 int dmalloc(void **p, size_t bytes) { *p = std::malloc(bytes ? bytes : 8); return *p ? 0 : 2; }

@@ -131,6 +131,25 @@ def test_emulated_batch_and_max_iter(S, O, emu):
     m.close()
 
 
+@pytest.mark.parametrize("alg,gi", [("CP", -4), ("CP", -8), ("CP", 4), ("SP", -3)])
+def test_emulated_eager_graph_iters_keep_the_buffer_rotation(S, O, emu, alg, gi):
+    """graph_iters < 0 selects eager launches of |graph_iters| iterations per poll; every repetition restarts at buffer slot 0,
+    so the count is rounded up to a multiple of 6 (CP: three z buffers x two v buffers) / an even number (SP) whatever its
+    sign -- a negative count that is not such a multiple used to give silently wrong iterates from the second repetition on."""
+    for kw in ({}, {"split_stage": 3}):
+        specs = S.get_server_heat_specs(7, 5, 2)
+        flat = S.flatten_problem(*specs)
+        a, oa = (S.CP, O.CP) if alg == "CP" else (S.SP, O.SP)
+        m = S.build_model(*specs, S.SolverOptions(a, None), lib_path=emu, max_iter=50, graph_iters=gi, **kw)
+        assert m.sizes.graph_iters % (6 if alg == "CP" else 2) == 0 and (m.sizes.graph_iters < 0) == (gi < 0)
+        r = S.solve_model(m, np.full(5, 0.1), tol=0.0)
+        o = O.Oracle(flat, oa)
+        ro = o.solve(np.full(5, 0.1), tol=0.0, max_iter=50)
+        assert r["iterations"] == ro["iterations"] == 50 and r["status"] == 1
+        assert relerr(m.solver_state.z, o.z) <= (1e-9 if alg == "CP" else 1e-6)
+        m.close()
+
+
 def test_emulated_build_products_match_oracle(S, O, emu):
     """The product's host build step (spock_host.cpp: eigen-decomposition based projector, explicit Rtilde
     inverse) against the oracle's (MGS projector, Cholesky solves): two independent routes to the same numbers."""

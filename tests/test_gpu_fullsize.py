@@ -1,0 +1,149 @@
+"""GPU parity at the STATED sizes of BASELINE.json configs 3, 4 and 5 (config 1 / 2 at full size: test_gpu_parity.py).
+
+  cfg3  server_heat nx = nu = 20, d = 3, reference N = 9 (6561 leaves): split lane-team geometry (81 subtrees + crown)
+  cfg4  examples/server_heat/mpc_simulation.jl:9-48: nx = nu = 20, d = 2, N = 10, 20 warm-started closed-loop steps, SP
+  cfg5  random linear system nx = 64, nu = 16, d = 2, N = 15 (16 384 leaves): 128 subtrees + 127-node crown, the sweep's
+        group-leaf vector in global memory (LaunchGeo::xl_global)
+
+All through the C ABI against the CPU oracle on the same inputs.  Tolerances: operators 1e-12, CP iterates / residual
+histories 1e-9 (relative to max(1, |ref|_inf)); SP whole solves are compared at the solve tolerance (SP trajectories are
+chaotic beyond ~40 iterations), their first iterations at rounding level.
+"""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _cp_block(S, O, specs, L_norm, iters, seed, op_tol=1e-12, it_tol=1e-9, **kw):
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, max_iter=iters, L_norm=L_norm, **kw)
+    o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm
+    rng = np.random.default_rng(seed)
+    x0 = np.full(flat.nx, 0.1)
+    for scale in (1.0, 0.05):
+        z = rng.standard_normal(flat.nz) * scale; v = rng.standard_normal(flat.nv) * scale
+        zo, vo = m.T(z, v, 0.3, 0.29, x0); zr, vr = o.T(z, v, 0.3, 0.29, x0)
+        assert np.isfinite(zo).all() and np.isfinite(vo).all()
+        assert relerr(zo, zr) <= op_tol and relerr(vo, vr) <= op_tol
+    assert relerr(m.L(z), o.L(z)) <= op_tol
+    assert relerr(m.L_transpose(v), o.Lt(v)) <= op_tol
+    assert relerr(m.prox_f(z, 0.1, x0), o.prox_f(z, 0.1, x0)) <= op_tol
+    assert relerr(m.prox_h_conj(v, 0.3), o.prox_h_conj(v, 0.3)) <= op_tol
+    # the same call sequence as the record that once read NaN (solve, reset, solve, then T on the same handle)
+    S.solve_model(m, x0, tol=0.0); m.reset()
+    r = S.solve_model(m, x0, tol=0.0)
+    ro = o.solve(x0, tol=0.0, max_iter=iters, history=iters + 2)
+    h = m.history()
+    assert r["iterations"] == ro["iterations"] == iters and r["status"] == ro["status"] == 1
+    assert np.max(np.abs(h["xi1"] - ro["hist_xi1"]) / ro["hist_xi1"]) <= it_tol
+    assert np.max(np.abs(h["xi2"] - ro["hist_xi2"]) / ro["hist_xi2"]) <= it_tol
+    assert relerr(m.solver_state.z, o.z) <= it_tol and relerr(m.solver_state.v, o.v) <= it_tol
+    zo, vo = m.T(z, v, 0.3, 0.29, x0)
+    assert relerr(zo, zr) <= op_tol and relerr(vo, vr) <= op_tol
+    sizes = m.sizes
+    m.close()
+    return flat, sizes
+
+
+def test_cfg3_full_size(S, O):
+    """BASELINE config 3: get_server_heat_specs(9, 20, 3) with p_ref fixed (the reference draws it from Julia's RNG,
+    server_heat.jl:90-94); ||L||^2 = 4 in closed form (the hard-coded 3.28 / 10 are not valid step sizes for d = 3)."""
+    specs = S.get_server_heat_specs(9, 20, 3, p_ref=[0.2, 0.3, 0.5])
+    flat, sizes = _cp_block(S, O, specs, "auto", 20, 31)
+    assert (flat.n, flat.nl, flat.nz, flat.nv) == (9841, 6561, 305061, 846282)
+    assert sizes.split_stage > 0 and sizes.n_subtrees == 3 ** sizes.split_stage    # the split lane-team geometry
+
+
+def test_cfg5_full_size(S, O):
+    """BASELINE config 5 at N = 15 (16 384 leaves): operator T, the four operators and 20 CP iterations against the oracle.
+    (A round-1 exploration log once read `T err nan` for this shape; it predates the final xl_global build and does not
+    reproduce -- this test pins the shape.)"""
+    specs = S.get_random_linear_specs(15, 64, 16)
+    flat, sizes = _cp_block(S, O, specs, "auto", 20, 51)
+    assert (flat.n, flat.nl, flat.nz, flat.nv) == (32767, 16384, 2506664, 6225670)
+    assert sizes.split_stage == 7 and sizes.n_subtrees == 128
+
+
+def test_cfg5_deep_crown_with_global_group_leaves(S, O):
+    """Crown of >= 2 levels with the group-leaf vector in global memory (xl_global) at a size the oracle runs in a second."""
+    specs = S.get_random_linear_specs(11, 64, 16)
+    for split in (4, 5):
+        _cp_block(S, O, specs, "auto", 12, 7 + split, split_stage=split)
+
+
+def _disturbances(nb, steps, d):
+    # the reference draws rand(1:d) (mpc_simulation.jl:170); here: numpy PCG64 seeded with the simulation index
+    return np.stack([np.random.default_rng(seed).integers(0, d, size=steps) for seed in range(nb)]).astype(np.int32)
+
+
+def test_cfg4_mpc_cp_full_size(S, O):
+    """mpc_simulation.jl's loop at its stated size (nx = nu = 20, N = 10, 20 steps) with CP, whose trajectories are
+    numerically stable: per-step iteration counts identical to the oracle-driven loop, trajectories to 1e-8."""
+    specs = S.get_server_heat_specs(10, 20, 2)
+    flat = S.flatten_problem(*specs)
+    nb, steps = 4, 20
+    w = _disturbances(nb, steps, 2)
+    x0 = 0.1 * (1.0 + 0.05 * np.arange(nb))[:, None] * np.ones((nb, 20))
+    m = S.build_model(*specs, S.SolverOptions(S.CP, None), batch=nb)
+    xt, ut, res = S.mpc_simulation(m, x0, w, tol=1e-3)
+    A, B = specs[2].A, specs[2].B
+    usl = flat.z_slices()["u"]
+    for b in range(nb):
+        o = O.Oracle(flat, O.CP)
+        x = x0[b].copy()
+        for t in range(steps):
+            r = o.solve(x, tol=1e-3)
+            u = o.z[usl][:20].copy()
+            assert (res[b][t]["iterations"], res[b][t]["status"]) == (r["iterations"], r["status"])
+            assert np.max(np.abs(xt[b, t] - x)) <= 1e-8 and np.max(np.abs(ut[b, t] - u)) <= 1e-8
+            x = A[w[b, t]] @ x + B[w[b, t]] @ u
+        assert np.max(np.abs(xt[b, steps] - x)) <= 1e-8
+    m.close()
+
+
+def test_cfg4_mpc_sp_full_size(S, O):
+    """BASELINE config 4 as the reference runs it: SolverOptions(SP, nothing), tol 1e-3, SILENT, 20 warm-started steps per
+    simulation (mpc_simulation.jl:40-54,164-177), here 4 simulations in one batch through spock_mpc_simulate.
+    SP trajectories are chaotic w.r.t. rounding beyond ~40 iterations, so whole solves agree with the oracle-driven loop at
+    the solve tolerance, not at rounding level: every step converges on both sides, the closed-loop states and inputs stay
+    within 5e-3 (absolute; |u| <= 0.13, tol = 1e-3) and the totals of SP iterations within 25 %.  The first solve's first 25
+    iterations are compared at rounding level (1e-9 for the first ten, 1e-6 = north_star's tolerance up to 25)."""
+    specs = S.get_server_heat_specs(10, 20, 2)
+    flat = S.flatten_problem(*specs)
+    nb, steps = 4, 20
+    w = _disturbances(nb, steps, 2)
+    x0 = np.full((nb, 20), 0.1)
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), batch=nb)
+    xt, ut, res = S.mpc_simulation(m, x0, w, tol=1e-3)
+    A, B = specs[2].A, specs[2].B
+    usl = flat.z_slices()["u"]
+    tot_g = tot_o = 0
+    for b in range(nb):
+        o = O.Oracle(flat, O.SP)
+        x = x0[b].copy()
+        for t in range(steps):
+            r = o.solve(x, tol=1e-3)
+            u = o.z[usl][:20].copy()
+            assert res[b][t]["status"] == r["status"] == 0
+            assert np.max(np.abs(xt[b, t] - x)) <= 5e-3 and np.max(np.abs(ut[b, t] - u)) <= 5e-3
+            tot_g += res[b][t]["iterations"]; tot_o += r["iterations"]
+            x = A[w[b, t]] @ x + B[w[b, t]] @ u
+        # the closed loop is stable: the state has contracted towards the origin
+        assert np.max(np.abs(xt[b, steps])) <= 0.05
+    assert abs(tot_g - tot_o) <= 0.25 * tot_o
+    m.close()
+    # first solve: rounding-level parity of the SP driver at this size while the trajectory is still well conditioned (at
+    # nx = 20 a rounding difference grows about tenfold every four SP iterations: 1e-16 at iteration 1, 1e-9 by 13, 1e-6 by 30)
+    m1 = S.build_model(*specs, S.SolverOptions(S.SP, None), max_iter=25)
+    S.solve_model(m1, x0[0], tol=1e-12, verbose=S.LOG)
+    o = O.Oracle(flat, O.SP)
+    ro = o.solve(x0[0], tol=1e-12, verbose=O.LOG, max_iter=25, history=40)
+    h = m1.history()
+    assert len(h["xi"]) == len(ro["hist_xi"]) == 25
+    rel = np.abs(h["xi"] - ro["hist_xi"]) / ro["hist_xi"]
+    assert np.max(rel[:10]) <= 1e-9 and np.max(rel) <= 1e-6      # north_star: iterates within 1e-6 relative
+    assert np.array_equal(h["backtrack"], ro["hist_backtrack"])
+    m1.close()
