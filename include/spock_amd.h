@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SPOCK_AMD_VERSION 100 /* round 1 */
+#define SPOCK_AMD_VERSION 200 /* round 2: spock_options_t.batch_layout, spock_sizes_t.interleaved */
 
 /* status codes */
 #define SPOCK_OK 0
@@ -95,6 +95,10 @@ typedef struct {
                            * negative -> ||L||^2 in closed form (the reference's `Todo: L norm must be computed efficiently!`) */
     int32_t max_iter;     /* 0 -> reference default: 5000 (cp.jl:190) / 1000 (sp.jl:360) */
     int32_t graph_iters;  /* iterations captured per hipGraph replay; 0 = choose */
+    int32_t batch_layout; /* layout of the batch in HBM: 0 = choose (element-major from 64 instances on, CP and the compile-time
+                           * shapes), 1 = instance-major z[b][nz] (one thread per tree node), 2 = element-major z[e][batch]
+                           * (one lane per instance, one wave per tree node).  Invisible at this boundary: every array that
+                           * crosses it is instance-major. */
 } spock_options_t;
 
 typedef struct {
@@ -112,7 +116,8 @@ typedef struct {
     int32_t z_x, z_u, z_s, z_tau, z_y;
     int32_t v1, v2, v3, v4, v5, v6, v7, v11, v12, v13, v14;
     int32_t split_stage, n_subtrees, graph_iters;
-    int32_t fused_iteration;  /* 1: a CP iteration runs as CROWN + SUB_BA (chosen per handle by timing), 0: SUB_A + CROWN + SUB_B / whole-tree kernel */
+    int32_t fused_iteration;  /* 1: a CP iteration runs as CROWN + SUB_BA (a deterministic rule on the shape), 0: SUB_A + CROWN + SUB_B / whole-tree kernel */
+    int32_t interleaved;      /* 1: the batch is held element-major (spock_options_t.batch_layout) */
 } spock_sizes_t;
 
 /* build_model(scen_tree, cost, dynamics, rms, constraints, SolverOptions(alg, nothing))

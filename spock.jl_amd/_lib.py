@@ -31,7 +31,7 @@ class Problem(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("algorithm", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("split_stage", C.c_int32),
-                ("L_norm", C.c_double), ("max_iter", C.c_int32), ("graph_iters", C.c_int32)]
+                ("L_norm", C.c_double), ("max_iter", C.c_int32), ("graph_iters", C.c_int32), ("batch_layout", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -43,7 +43,7 @@ class Sizes(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
                 ("n", "n_nonleaf", "n_leaf", "nz", "nv", "batch", "z_x", "z_u", "z_s", "z_tau", "z_y",
                  "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v11", "v12", "v13", "v14",
-                 "split_stage", "n_subtrees", "graph_iters", "fused_iteration")]
+                 "split_stage", "n_subtrees", "graph_iters", "fused_iteration", "interleaved")]
 
 
 # every symbol include/spock_amd.h declares: (restype, argtypes)

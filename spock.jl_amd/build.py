@@ -11,8 +11,16 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["spock_kernels.hip", "spock_abi.cpp", "spock_host.cpp", "spock_rt_hip.cpp"]
-HEADERS = ["spock_device.hpp", "spock_group.hpp", "spock_internal.hpp", "spock_rt.hpp", "spock_sp.hpp", "spock_team_local.hpp", os.path.join("..", "..", "include", "spock_amd.h")]
+SOURCES = ["spock_kernels.hip", "spock_ikernels.hip", "spock_abi.cpp", "spock_host.cpp", "spock_rt_hip.cpp"]
+HEADERS = ["spock_device.hpp", "spock_group.hpp", "spock_igroup.hpp", "spock_shapes.hpp", "spock_internal.hpp", "spock_rt.hpp", "spock_sp.hpp", "spock_team_local.hpp", os.path.join("..", "..", "include", "spock_amd.h")]
+_API = os.path.join("..", "..", "include", "spock_amd.h")
+DEPS = {   # headers each translation unit includes
+    "spock_kernels.hip": ["spock_device.hpp", "spock_group.hpp", "spock_team_local.hpp", "spock_sp.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
+    "spock_ikernels.hip": ["spock_device.hpp", "spock_igroup.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
+    "spock_abi.cpp": ["spock_internal.hpp", "spock_rt.hpp", _API],
+    "spock_host.cpp": ["spock_internal.hpp"],
+    "spock_rt_hip.cpp": ["spock_rt.hpp"],
+}
 OUT = os.path.join(HERE, "libspock_amd.so")
 
 
@@ -38,13 +46,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     tmp = os.path.join(HERE, "build")
     os.makedirs(tmp, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable", "-Wno-cuda-compat"]
-    for s in SOURCES:
+    def compile_one(s):
         o = os.path.join(tmp, s + ".o")
         cmd = [_hipcc()] + flags + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(o)
+        # recompile only what changed
+        deps = [os.path.join(CSRC, s)] + [os.path.join(CSRC, h) for h in DEPS[s]]
+        if force or not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in deps):
+            subprocess.check_call(cmd)
+        return o
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:   # the two kernel files take minutes each: side by side
+        objs = list(ex.map(compile_one, SOURCES))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd))

@@ -31,6 +31,13 @@ struct spock_handle_s {
     int alg = SPOCK_ALG_CP, device = 0, batch = 1, max_iter = 5000, graph_iters = 32;
     double L_norm = 10.;
     void *stream = nullptr, *ev0 = nullptr, *ev1 = nullptr, *graph = nullptr;
+    // element-major regime: the tiles are split into groups that run their kernel chains on streams of their own -- the crown
+    // chain of one group (latency-bound, a handful of workgroups) then overlaps the bottom-layer kernel of the others
+    int n_tg = 1;
+    std::vector<void *> tg_stream, tg_event;
+    void *ev_fork = nullptr;
+    void *graph_log = nullptr;   // element-major CP: LOG-mode solves run another kernel variant (KArgs::want_xi), hence another graph
+    int want_xi = 0;
     // device memory
     double *d_mats = nullptr, *d_z[3] = {nullptr, nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}, *d_v2x = nullptr;
     bool lat_regime = false;   // few workgroups in flight (register-resident sweep): SUB_B runs as MODE_SUB_B_LAT
@@ -38,6 +45,12 @@ struct spock_handle_s {
     bool fused = false;   // CP iteration = CROWN + SUB_BA (after one SUB_A) instead of SUB_A + CROWN + SUB_B
     double *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_partials = nullptr, *d_x0 = nullptr, *d_hist = nullptr;
     double *d_xlbuf = nullptr;
+    // element-major batched regime (spock_igroup.hpp): the iterate as [element][bp]; d_z / d_v then serve as instance-major
+    // staging buffers of the API (get / set state)
+    bool ilv = false;
+    long bpad = 0;   // batch rounded up to a multiple of 64
+    double *i_z[3] = {nullptr, nullptr, nullptr}, *i_v[2] = {nullptr, nullptr}, *i_cq = nullptr;
+    bool stage_valid = false;   // d_z[0] / d_v[0] hold the instance-major copy of the current state
     Ctl *d_ctl = nullptr;
     unsigned long long *d_dbg = nullptr;
     int hist_cap = 0;
@@ -102,6 +115,12 @@ KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
         a.hist = nullptr; a.hist_cap = 0; a.batch = 1;
     }
     a.stride_z = h->bp.dm.nz; a.stride_v = h->bp.dm.nv;
+    if (!op && h->ilv) {
+        a.z_in = h->i_z[parity % 3]; a.v_in = h->i_v[parity % 2];
+        a.z_out = h->i_z[(parity + 1) % 3]; a.v_out = h->i_v[(parity + 1) % 2];
+        a.z_next = h->i_z[(parity + 2) % 3];
+        a.ilv = 1; a.bp = h->bpad; a.cq = h->i_cq; a.want_xi = h->want_xi;
+    }
     a.xlbuf = h->d_xlbuf;
     a.parity = parity;
     a.flags = flags;
@@ -122,18 +141,54 @@ int launch_iteration(spock_handle_s *h, bool op, int parity, unsigned flags, boo
 // CP driver: the kernels of iteration k (k taken modulo 6).  Fused sequence: SUB_A of iteration 0 is launched once per
 // solve (cp_prologue); every iteration is then CROWN + SUB_BA, the latter already running phase A and the backward
 // sweep of iteration k + 1.
-int launch_cp_iteration(spock_handle_s *h, int k, unsigned flags = 0) {
-    const KArgs a = make_args(h, false, k % 6, flags);
-    if (h->bp.dm.t0 == 0) return launch_group(MODE_FULL, a, h->stream);
+int launch_cp_iteration(spock_handle_s *h, int k, unsigned flags = 0, void *stream = nullptr, int tile0 = 0, int n_tiles = 0) {
+    KArgs a = make_args(h, false, k % 6, flags);
+    if (!stream) stream = h->stream;
+    if (h->bp.dm.t0 == 0) return launch_group(MODE_FULL, a, stream);
+    if (h->ilv) {   // element-major regime: hierarchy of groups (spock_igroup.hpp): UP the mid layers, TOP, DOWN the mid layers, bottom
+        const Dims &dm = h->bp.dm;
+        a.tile0 = tile0; a.n_tiles = n_tiles;
+        int e = 0;
+        for (int lv = dm.n_lv - 2; lv >= 1 && e == 0; --lv) { a.grp_level = lv; e = launch_group(MODE_I_UP, a, stream); }
+        a.grp_level = 0;
+        if (e == 0) e = launch_group(MODE_CROWN, a, stream);
+        for (int lv = 1; lv <= dm.n_lv - 2 && e == 0; ++lv) { a.grp_level = lv; e = launch_group(MODE_I_DOWN, a, stream); }
+        a.grp_level = 0;
+        if (e == 0) e = launch_group(MODE_SUB_BA, a, stream);
+        return e;
+    }
     int e = 0;
-    if (!h->fused) e = launch_group(MODE_SUB_A, a, h->stream);
-    if (e == 0) e = launch_group(MODE_CROWN, a, h->stream);
-    if (e == 0) e = launch_group(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), a, h->stream);
+    if (!h->fused) e = launch_group(MODE_SUB_A, a, stream);
+    if (e == 0) e = launch_group(MODE_CROWN, a, stream);
+    if (e == 0) e = launch_group(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), a, stream);
+    return e;
+}
+// G iterations of every instance.  Element-major regime with several tile groups: fork from the handle's stream, one chain of G
+// iterations per group on its own stream, join (the same calls build parallel branches when the handle's stream is capturing).
+int launch_cp_iterations(spock_handle_s *h, int G) {
+    if (!h->ilv || h->n_tg <= 1) {
+        int e = 0;
+        for (int it = 0; it < G && e == 0; ++it) e = launch_cp_iteration(h, it);
+        return e;
+    }
+    const int tiles = (int)(h->bpad / 64);
+    int e = rt::event_record(h->ev_fork, h->stream);
+    for (int gi = 0; gi < h->n_tg && e == 0; ++gi) {
+        const int t_lo = (int)((long)tiles * gi / h->n_tg), t_hi = (int)((long)tiles * (gi + 1) / h->n_tg);
+        if (t_hi <= t_lo) continue;
+        void *st = h->tg_stream[gi];
+        e = rt::stream_wait_event(st, h->ev_fork);
+        for (int it = 0; it < G && e == 0; ++it) e = launch_cp_iteration(h, it, 0, st, t_lo, t_hi - t_lo);
+        if (e == 0) e = rt::event_record(h->tg_event[gi], st);
+        if (e == 0) e = rt::stream_wait_event(h->stream, h->tg_event[gi]);
+    }
     return e;
 }
 int cp_prologue(spock_handle_s *h, unsigned flags = 0) {
     if (!h->fused) return 0;
-    return launch_group(MODE_SUB_A, make_args(h, false, 0, flags), h->stream);
+    int e = launch_group(MODE_SUB_A, make_args(h, false, 0, flags), h->stream);
+    if (e == 0 && h->ilv) e = launch_group(MODE_ICROWN_A, make_args(h, false, 0, flags), h->stream);
+    return e;
 }
 
 int ensure_op_buffers(spock_handle_s *h) {
@@ -171,6 +226,7 @@ Ctl fresh_ctl(const spock_handle_s *h, double gamma, double sigma, double tol, i
 int time_cp_sequences(spock_handle_s *h);
 int choose_cp_sequence(spock_handle_s *h) {
     const Dims &dm = h->bp.dm;
+    if (h->ilv) { h->fused = true; return 0; }   // the element-major regime has the fused sequence only
     h->fused = dm.t0 > 0 && (dm.nx + dm.nu <= 8);
     if (std::getenv("SPOCK_AMD_NO_FUSE")) { h->fused = false; return 0; }
     if (const char *e = std::getenv("SPOCK_AMD_FUSE")) {
@@ -208,6 +264,22 @@ int time_cp_sequences(spock_handle_s *h) {
     for (auto &x : cs) x.done = 1;
     if (!e) e = rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream);
     if (!e) e = rt::sync(h->stream);
+    return e;
+}
+
+// element-major regime: the API's instance-major view of the state lives in the staging buffers d_z[0] / d_v[0]
+int ilv_state_to_stage(spock_handle_s *h) {
+    if (h->stage_valid) return 0;
+    const Dims &dm = h->bp.dm;
+    int e = launch_transpose(h->d_z[0], h->i_z[0], dm.nz, h->batch, h->bpad, dm.nz, h->stream);
+    if (!e) e = launch_transpose(h->d_v[0], h->i_v[0], dm.nv, h->batch, h->bpad, dm.nv, h->stream);
+    if (!e) h->stage_valid = true;
+    return e;
+}
+int ilv_stage_to_state(spock_handle_s *h) {
+    const Dims &dm = h->bp.dm;
+    int e = launch_transpose(h->i_z[0], h->d_z[0], h->batch, dm.nz, dm.nz, h->bpad, h->stream);
+    if (!e) e = launch_transpose(h->i_v[0], h->d_v[0], h->batch, dm.nv, dm.nv, h->bpad, h->stream);
     return e;
 }
 
@@ -437,9 +509,31 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     int split = o ? o->split_stage : 0;
     if (const char *e = std::getenv("SPOCK_AMD_SPLIT_STAGE")) split = std::atoi(e);
 
+    // Layout of the batch: element-major (one lane per instance, spock_igroup.hpp) pays off once a wave's 64 lanes are
+    // filled, i.e. from 64 instances on; it exists for CP and the compile-time shapes.  batch_layout / SPOCK_AMD_ILV override.
+    int layout = o ? o->batch_layout : 0;
+    if (const char *e = std::getenv("SPOCK_AMD_ILV")) layout = (e[0] == '1') ? 2 : 1;
+    if (layout < 0 || layout > 2) { delete h; return fail(SPOCK_ERR_BAD_ARG, "batch_layout must be 0 (choose), 1 (instance-major) or 2 (element-major)"); }
+    const bool ilv_possible = alg == SPOCK_ALG_CP && N >= 3 && have_static_variant(nx, nu, d, ny) && hp.nQ == 1 && hp.nR == 1 && hp.nQN == 1;
+    if (layout == 2 && !ilv_possible) { delete h; return fail(SPOCK_ERR_UNSUPPORTED, "the element-major batch layout exists for CP, the compile-time shapes and shared cost matrices"); }
+    bool want_ilv = ilv_possible && (layout == 2 || (layout == 0 && h->batch >= 64));
+
     bool unsupported = false;
-    const std::string msg = host_build(hp, split, h->bp, unsupported, h->batch);
+    std::string msg;
+    if (want_ilv) {
+        const int isplit = split > 0 ? split : choose_split_stage_ilv(N, d, nx);
+        // (buffer addressing: 32-bit byte offsets inside an array)
+        long nvv = 0; { long nn_ = (nl - 1) / (d - 1); nvv = nn_ * ny + nn_ + (long)(nx + nu + 2) * (n - 1) + nn_ * (nx + nu) + nl * (2L * nx + 2); }
+        const bool small = nvv * (((long)(h->batch + 63) / 64) * 64) * 8 < (1L << 32) - 4096;
+        const bool fits = small && isplit >= 1 && isplit <= N - 2 && (long)group_threads(d, N - isplit) * nx * 64 * 8 <= 56 * 1024;
+        msg = fits ? host_build(hp, isplit, h->bp, unsupported, h->batch) : std::string("subtree does not fit the element-major kernels' LDS slots");
+        if (!msg.empty() && layout == 2) { delete h; return fail(SPOCK_ERR_UNSUPPORTED, msg); }
+        if (!msg.empty()) want_ilv = false;   // chosen automatically: fall back to the instance-major kernels
+    }
+    if (!want_ilv) msg = host_build(hp, split, h->bp, unsupported, h->batch);
     if (!msg.empty()) { delete h; return fail(unsupported ? SPOCK_ERR_UNSUPPORTED : SPOCK_ERR_BUILD, msg); }
+    h->ilv = want_ilv;
+    h->bpad = want_ilv ? ((long)(h->batch + 63) / 64) * 64 : 0;
     if (o && o->L_norm < 0.) h->L_norm = h->bp.L_norm_closed * (1. + 1e-9);   // negative: closed form instead of the hard-coded constant
     const Dims &dm = h->bp.dm;
 
@@ -456,7 +550,25 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     const size_t B = (size_t)h->batch;
     if ((e = dev_alloc(h, &h->d_mats, h->bp.mats.size()))) return bail(e, "hipMalloc(matrix pool)");
     if ((e = rt::h2d(h->d_mats, h->bp.mats.data(), h->bp.mats.size() * sizeof(double), h->stream))) return bail(e, "upload");
-    if (alg == SPOCK_ALG_CP) {
+    const size_t W = h->ilv ? (size_t)h->bpad : B;   // columns of the per-instance work arrays
+    if (alg == SPOCK_ALG_CP && h->ilv) {
+        if ((e = dev_alloc(h, &h->d_z[0], B * dm.nz)) || (e = dev_alloc(h, &h->d_v[0], B * dm.nv))) return bail(e, "hipMalloc(staging)");
+        for (int k = 0; k < 3; ++k) if ((e = dev_alloc(h, &h->i_z[k], W * dm.nz))) return bail(e, "hipMalloc(state)");
+        for (int k = 0; k < 2; ++k) if ((e = dev_alloc(h, &h->i_v[k], W * dm.nv))) return bail(e, "hipMalloc(state)");
+        if ((e = dev_alloc(h, &h->i_cq, W * (size_t)(group_threads(dm.d, dm.t0 + 1) + dm.nsub) * dm.nx))) return bail(e, "hipMalloc(state)");
+        h->stage_valid = true;
+        {   // tile groups: at least four tiles per group, at most four groups
+            const int tiles = (int)(h->bpad / 64);
+            h->n_tg = tiles >= 16 ? 4 : (tiles >= 8 ? 2 : 1);
+            if (const char *e2 = std::getenv("SPOCK_AMD_ILV_TGROUPS")) { h->n_tg = std::atoi(e2); if (h->n_tg < 1) h->n_tg = 1; if (h->n_tg > tiles) h->n_tg = tiles; if (h->n_tg > 8) h->n_tg = 8; }
+            if (h->n_tg > 1) {
+                if ((e = rt::event_create(&h->ev_fork))) return bail(e, "hipEventCreate");
+                h->tg_stream.assign(h->n_tg, nullptr); h->tg_event.assign(h->n_tg, nullptr);
+                for (int gi = 0; gi < h->n_tg; ++gi)
+                    if ((e = rt::stream_create(&h->tg_stream[gi])) || (e = rt::event_create(&h->tg_event[gi]))) return bail(e, "hipStreamCreate");
+            }
+        }
+    } else if (alg == SPOCK_ALG_CP) {
         for (int k = 0; k < 3; ++k) if ((e = dev_alloc(h, &h->d_z[k], B * dm.nz))) return bail(e, "hipMalloc(state)");
         for (int k = 0; k < 2; ++k) if ((e = dev_alloc(h, &h->d_v[k], B * dm.nv))) return bail(e, "hipMalloc(state)");
         if ((e = dev_alloc(h, &h->d_v2x, B * (size_t)dm.nsub))) return bail(e, "hipMalloc(state)");
@@ -470,9 +582,11 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
             return bail(e, "hipMalloc(SP state)");
     }
     h->hist_cap = h->max_iter + 2;
-    if ((e = dev_alloc(h, &h->d_dbuf, B * dm.nn * dm.nu)) || (e = dev_alloc(h, &h->d_qroot, B * dm.nsub * dm.nx)) ||
-        (e = dev_alloc(h, &h->d_cbuf, B * (size_t)(group_threads(dm.d, dm.t0 + 1) + 1) * (dm.nx + dm.nu))) ||
-        (e = dev_alloc(h, &h->d_partials, B * (dm.nsub + 1) * kPartialStride)) || (e = dev_alloc(h, &h->d_x0, B * dm.nx)) ||
+    const size_t n_part = h->ilv ? (size_t)(h->bpad / 64) * (size_t)(dm.nsub + dm.n_crown_groups) * 3 * 64
+                                 : B * (dm.nsub + 1) * kPartialStride;
+    if ((e = dev_alloc(h, &h->d_dbuf, W * dm.nn * dm.nu)) || (e = dev_alloc(h, &h->d_qroot, W * dm.nsub * dm.nx)) ||
+        (e = dev_alloc(h, &h->d_cbuf, W * (size_t)(group_threads(dm.d, dm.t0 + 1) + 1) * (dm.nx + dm.nu))) ||
+        (e = dev_alloc(h, &h->d_partials, n_part)) || (e = dev_alloc(h, &h->d_x0, B * dm.nx)) ||
         (e = dev_alloc(h, &h->d_hist, B * (size_t)h->hist_cap * kHistStride)) || (e = dev_alloc(h, &h->d_ctl, B)) ||
         (e = dev_alloc(h, &h->d_dbg, (size_t)3 * 64 * 2)))
         return bail(e, "hipMalloc(workspace)");
@@ -499,6 +613,10 @@ int spock_destroy(spock_handle_t h) {
     DeviceGuard guard(h->device);
     if (h->stream) rt::sync(h->stream);
     if (h->graph) rt::graph_destroy(h->graph);
+    if (h->graph_log) rt::graph_destroy(h->graph_log);
+    for (void *st : h->tg_stream) if (st) { rt::sync(st); rt::stream_destroy(st); }
+    for (void *ev : h->tg_event) if (ev) rt::event_destroy(ev);
+    if (h->ev_fork) rt::event_destroy(h->ev_fork);
     for (void *p : h->allocs) rt::dfree(p);
     if (h->ev0) rt::event_destroy(h->ev0);
     if (h->ev1) rt::event_destroy(h->ev1);
@@ -516,6 +634,7 @@ int spock_sizes(spock_handle_t h, spock_sizes_t *s) {
     s->v11 = dm.o11; s->v12 = dm.o12; s->v13 = dm.o13; s->v14 = dm.o14;
     s->split_stage = dm.t0; s->n_subtrees = dm.nsub; s->graph_iters = h->graph_iters;
     s->fused_iteration = h->fused ? 1 : 0;
+    s->interleaved = h->ilv ? 1 : 0;
     return SPOCK_OK;
 }
 
@@ -565,7 +684,9 @@ int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const 
             std::memset(&a, 0, sizeof(a));
             a.dm = dm; a.mats = h->d_mats; a.x0 = h->d_x0; a.w_seq = d_w; a.x_traj = d_xt; a.u_traj = d_ut;
             a.t = t; a.steps = steps; a.batch = h->batch;
+            a.stride_e = 1;
             if (h->alg == SPOCK_ALG_SP) { a.z = h->s_vec[0]; a.stride_z = (long)dm.nz + dm.nv; }
+            else if (h->ilv) { a.z = h->i_z[0]; a.stride_z = 1; a.stride_e = h->bpad; }
             else { a.z = h->d_z[0]; a.stride_z = dm.nz; }
             e = launch_mpc_advance(a, h->stream);
             if (e) rc = fail(SPOCK_ERR_HIP, rt::err(e));
@@ -596,29 +717,33 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
     if (z0) {
         RTCHECK(rt::h2d(h->d_z[0], z0, B * dm.nz * sizeof(double), h->stream));
         RTCHECK(rt::h2d(h->d_v[0], v0, B * dm.nv * sizeof(double), h->stream));
+        if (h->ilv) RTCHECK(ilv_stage_to_state(h));
     }
+    h->stage_valid = false;
     h->h_ctl.assign(B, fresh_ctl(h, gamma, sigma, tol, verbose));
     RTCHECK(rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream));
 
     const int G = h->graph_iters > 0 ? h->graph_iters : -h->graph_iters;   // negative: eager launches
     const bool use_graph = h->graph_iters > 0 && rt::graphs_supported();
-    if (use_graph && !h->graph) {
+    h->want_xi = (h->ilv && verbose == SPOCK_LOG) ? 1 : 0;
+    void *&graph = h->want_xi ? h->graph_log : h->graph;
+    if (use_graph && !graph) {
         RTCHECK(rt::capture_begin(h->stream));
         int e = 0;
-        for (int it = 0; it < G && e == 0; ++it) e = launch_cp_iteration(h, it);
+        e = launch_cp_iterations(h, G);
         void *exec = nullptr;
         const int e2 = rt::capture_end(h->stream, &exec);
         if (e) return fail(SPOCK_ERR_HIP, std::string("kernel launch during capture: ") + rt::err(e));
         if (e2) return fail(SPOCK_ERR_HIP, std::string("hipStreamEndCapture/hipGraphInstantiate: ") + rt::err(e2));
-        h->graph = exec;
+        graph = exec;
     }
     RTCHECK(rt::event_record(h->ev0, h->stream));
     RTCHECK(cp_prologue(h));
     const int max_reps = (h->max_iter + 1 + G - 1) / G + 2;
     bool all_done = false;
     for (int rep = 0; rep < max_reps && !all_done; ++rep) {
-        if (use_graph) RTCHECK(rt::graph_launch(h->graph, h->stream));
-        else for (int it = 0; it < G; ++it) RTCHECK(launch_cp_iteration(h, it));
+        if (use_graph) RTCHECK(rt::graph_launch(graph, h->stream));
+        else RTCHECK(launch_cp_iterations(h, G));
         RTCHECK(launch_group(MODE_FINALIZE, make_args(h, false, 0, 0), h->stream));
         RTCHECK(rt::d2h(h->h_ctl.data(), h->d_ctl, B * sizeof(Ctl), h->stream));
         RTCHECK(rt::sync(h->stream));
@@ -634,15 +759,21 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
     int evals = 0;
     bool same_parity = true;   // every instance stopped at the same iteration (always with tol = 0): one copy per array
     for (size_t b = 1; b < B; ++b) same_parity = same_parity && h->h_ctl[b].result_parity == h->h_ctl[0].result_parity;
-    if (same_parity) {
+    if (h->ilv) {
+        const int rp = h->h_ctl[0].result_parity;
+        if (same_parity) {
+            if (rp % 3) RTCHECK(rt::d2d(h->i_z[0], h->i_z[rp % 3], (size_t)h->bpad * dm.nz * sizeof(double), h->stream));
+            if (rp % 2) RTCHECK(rt::d2d(h->i_v[0], h->i_v[1], (size_t)h->bpad * dm.nv * sizeof(double), h->stream));
+        } else RTCHECK(launch_ilv_collect(h->i_z, h->i_v, h->d_ctl, dm.nz, dm.nv, h->bpad, h->batch, h->stream));
+    } else if (same_parity) {
         const int rp = h->h_ctl[0].result_parity;
         if (rp % 3) RTCHECK(rt::d2d(h->d_z[0], h->d_z[rp % 3], B * dm.nz * sizeof(double), h->stream));
         if (rp % 2) RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * dm.nv * sizeof(double), h->stream));
     }
     for (size_t b = 0; b < B; ++b) {
         const Ctl &c = h->h_ctl[b];
-        if (!same_parity && c.result_parity % 3) RTCHECK(rt::d2d(h->d_z[0] + b * dm.nz, h->d_z[c.result_parity % 3] + b * dm.nz, sizeof(double) * dm.nz, h->stream));
-        if (!same_parity && c.result_parity % 2) RTCHECK(rt::d2d(h->d_v[0] + b * dm.nv, h->d_v[1] + b * dm.nv, sizeof(double) * dm.nv, h->stream));
+        if (!h->ilv && !same_parity && c.result_parity % 3) RTCHECK(rt::d2d(h->d_z[0] + b * dm.nz, h->d_z[c.result_parity % 3] + b * dm.nz, sizeof(double) * dm.nz, h->stream));
+        if (!h->ilv && !same_parity && c.result_parity % 2) RTCHECK(rt::d2d(h->d_v[0] + b * dm.nv, h->d_v[1] + b * dm.nv, sizeof(double) * dm.nv, h->stream));
         if (c.evals > evals) evals = c.evals;
         if (results) {
             spock_result_t &r = results[b];
@@ -666,6 +797,7 @@ int spock_get_z(spock_handle_t h, double *z_out) {
         RTCHECK(rt::sync(h->stream));
         return SPOCK_OK;
     }
+    if (h->ilv) RTCHECK(ilv_state_to_stage(h));
     RTCHECK(rt::d2h(z_out, h->d_z[0], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
@@ -680,6 +812,7 @@ int spock_get_v(spock_handle_t h, double *v_out) {
         RTCHECK(rt::sync(h->stream));
         return SPOCK_OK;
     }
+    if (h->ilv) RTCHECK(ilv_state_to_stage(h));
     RTCHECK(rt::d2h(v_out, h->d_v[0], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
@@ -698,6 +831,7 @@ int spock_set_state(spock_handle_t h, const double *z, const double *v) {
     }
     RTCHECK(rt::h2d(h->d_z[0], z, (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
     RTCHECK(rt::h2d(h->d_v[0], v, (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
+    if (h->ilv) { RTCHECK(ilv_stage_to_state(h)); h->stage_valid = true; }
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
 }
@@ -705,6 +839,15 @@ int spock_reset(spock_handle_t h) {
     if (!h) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
     DeviceGuard guard(h->device);
     if (h->alg == SPOCK_ALG_SP) { RTCHECK(sp_init_state(h)); return SPOCK_OK; }
+    if (h->ilv) {
+        for (int k = 0; k < 3; ++k) RTCHECK(rt::dzero(h->i_z[k], (size_t)h->bpad * h->bp.dm.nz * sizeof(double), h->stream));
+        for (int k = 0; k < 2; ++k) RTCHECK(rt::dzero(h->i_v[k], (size_t)h->bpad * h->bp.dm.nv * sizeof(double), h->stream));
+        RTCHECK(rt::dzero(h->d_z[0], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
+        RTCHECK(rt::dzero(h->d_v[0], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
+        h->stage_valid = true;
+        RTCHECK(rt::sync(h->stream));
+        return SPOCK_OK;
+    }
     for (int k = 0; k < 3; ++k) RTCHECK(rt::dzero(h->d_z[k], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
     for (int k = 0; k < 2; ++k) RTCHECK(rt::dzero(h->d_v[k], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
     RTCHECK(rt::sync(h->stream));
@@ -807,19 +950,22 @@ int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_
     const bool split = h->bp.dm.t0 > 0;
     unsigned dbg = 0;
     if (const char *e = std::getenv("SPOCK_AMD_DEBUG_FLAGS")) dbg = (unsigned)std::atoi(e);
-    std::vector<int> seq;   // (mode, iteration) of every launch, in order
-    std::vector<int> seq_it;
-    if (split && h->fused) { seq.push_back(MODE_SUB_A); seq_it.push_back(0); }
+    std::vector<int> seq, seq_it, seq_lv;   // (mode, iteration, layer of mid groups) of every launch, in order
+    auto push = [&](int mode, int it, int lv = 0) { seq.push_back(mode); seq_it.push_back(it); seq_lv.push_back(lv); };
+    if (split && h->fused) { push(MODE_SUB_A, 0); if (h->ilv) push(MODE_ICROWN_A, 0); }
     for (int it = 0; it < reps; ++it) {
-        if (!split) { seq.push_back(MODE_FULL); seq_it.push_back(it); continue; }
-        if (!h->fused) { seq.push_back(MODE_SUB_A); seq_it.push_back(it); }
-        seq.push_back(MODE_CROWN); seq_it.push_back(it);
-        seq.push_back(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B)); seq_it.push_back(it);
+        if (!split) { push(MODE_FULL, it); continue; }
+        if (!h->fused) push(MODE_SUB_A, it);
+        if (h->ilv) for (int lv = h->bp.dm.n_lv - 2; lv >= 1; --lv) push(MODE_I_UP, it, lv);
+        push(MODE_CROWN, it);
+        if (h->ilv) for (int lv = 1; lv <= h->bp.dm.n_lv - 2; ++lv) push(MODE_I_DOWN, it, lv);
+        push(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), it);
     }
     std::vector<void *> ev(seq.size() * 2, nullptr);
     for (auto &e : ev) RTCHECK(rt::event_create(&e));
     for (size_t k = 0; k < seq.size(); ++k) {
-        const KArgs a = make_args(h, false, seq_it[k] % 6, dbg);
+        KArgs a = make_args(h, false, seq_it[k] % 6, dbg);
+        a.grp_level = seq_lv[k];
         RTCHECK(rt::event_record(ev[2 * k], h->stream));
         RTCHECK(launch_group(seq[k], a, h->stream));
         RTCHECK(rt::event_record(ev[2 * k + 1], h->stream));
@@ -830,14 +976,21 @@ int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_
     for (size_t k = 0; k < seq.size(); ++k) {
         float ms = 0.f;
         RTCHECK(rt::event_elapsed(&ms, ev[2 * k], ev[2 * k + 1]));
-        const int kind = seq[k] == MODE_SUB_A ? 0 : seq[k] == MODE_CROWN ? 1 : seq[k] == MODE_FULL ? 3 : 2;
+        // (element-major regime: the crown's node-local kernels count with the crown, kind 1)
+        const int kind = (seq[k] == MODE_SUB_A || seq[k] == MODE_ICROWN_A) ? 0 : (seq[k] == MODE_CROWN || seq[k] == MODE_I_UP || seq[k] == MODE_I_DOWN) ? 1 : seq[k] == MODE_FULL ? 3 : 2;
         sum[kind] += ms; cnt[kind] += 1;
     }
     for (auto e : ev) rt::event_destroy(e);
     for (int q = 0; q < 4; ++q) { avg_ms[q] = cnt[q] ? sum[q] / cnt[q] : 0.; if (launches) launches[q] = cnt[q]; }
     // leave a consistent state behind: the iterate after `reps` iterations goes back to slot 0
-    if (reps % 3) RTCHECK(rt::d2d(h->d_z[0], h->d_z[reps % 3], B * h->bp.dm.nz * sizeof(double), h->stream));
-    if (reps % 2) RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * h->bp.dm.nv * sizeof(double), h->stream));
+    if (h->ilv) {
+        if (reps % 3) RTCHECK(rt::d2d(h->i_z[0], h->i_z[reps % 3], (size_t)h->bpad * h->bp.dm.nz * sizeof(double), h->stream));
+        if (reps % 2) RTCHECK(rt::d2d(h->i_v[0], h->i_v[1], (size_t)h->bpad * h->bp.dm.nv * sizeof(double), h->stream));
+        h->stage_valid = false;
+    } else {
+        if (reps % 3) RTCHECK(rt::d2d(h->d_z[0], h->d_z[reps % 3], B * h->bp.dm.nz * sizeof(double), h->stream));
+        if (reps % 2) RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * h->bp.dm.nv * sizeof(double), h->stream));
+    }
     for (auto &x : cs) x.done = 1;
     RTCHECK(rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream));
     RTCHECK(rt::sync(h->stream));

@@ -122,8 +122,8 @@ SPK_DEV double spk_clamp(double x, double lo, double hi) { return x > hi ? hi : 
 SPK_DEV int slot_event(int c, int d) { return (2 + c) % d; }
 
 // y (+)= S x for a symmetric cost square root S (n x n)
-template <class P, bool ACC>
-SPK_DEV void sym_mv(int n, MatPtr S, const double *x, double *y) {
+template <class P, bool ACC, class XV>
+SPK_DEV void sym_mv(int n, MatPtr S, XV x, double *y) {
     SPK_UNROLL for (int r = 0; r < n; ++r) {
         double t;
         if (P::DIAG) t = S[r + r * n] * x[r];
@@ -153,6 +153,103 @@ SPK_DEV void project_soc(double *vec, int len) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pointer-like views.  The node-local bodies below are written against `operator[]` on their vector arguments, so the same
+// code runs on two layouts of the iterate:
+//   * instance-major  z[b][nz]  (plain pointers): one THREAD per tree node -- latency regime, operators, SP
+//   * element-major   z[e][Bp]  (IVec): one LANE per problem instance, one WAVE per tree node -- the batched regime of
+//     BASELINE config 2, where every load / store of a wave is 512 contiguous bytes and every matrix element is wave-uniform
+// IVec element e of this lane's instance lives at base[e * stride] + lane, `base` wave-uniform.
+#ifdef SPOCK_HOST_EMU
+struct IVec {
+    double *base;
+    long stride;
+    unsigned lb;
+    SPK_DEV double &operator[](long e) const { return *(double *)((char *)(base + e * stride) + lb); }
+    SPK_DEV IVec operator+(long off) const { return IVec{base + off * stride, stride, lb}; }
+    SPK_DEV explicit operator bool() const { return base != nullptr; }
+};
+// view of `n_elems` element rows starting at the tile's first column `base_tile`, for lane `lane`
+SPK_DEV IVec ivec_make(const double *base_tile, long stride, int lane, long) { return IVec{const_cast<double *>(base_tile), stride, (unsigned)lane * 8u}; }
+SPK_DEV IVec ivec_null() { return IVec{nullptr, 0, 0}; }
+#else
+// gfx950: buffer addressing.  address = resource base (4 SGPRs, the array's tile column) + soffset (one SGPR: the element row,
+// e * stride * 8 bytes, scalar arithmetic) + voffset (one VGPR for the whole kernel: lane * 8): no per-row vector or 64-bit
+// scalar address arithmetic at all.  Offsets are 32-bit: an array must stay below 4 GiB (checked at spock_create).
+typedef unsigned int spk_u32x2 __attribute__((ext_vector_type(2)));
+struct IBufRef {
+    __amdgpu_buffer_rsrc_t r;
+    unsigned voff, soff;
+    SPK_DEV operator double() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+    SPK_DEV void operator=(double v) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(spk_u32x2, v), r, voff, soff, 0); }
+};
+struct IVec {
+    __amdgpu_buffer_rsrc_t r;
+    unsigned stride8, voff, soff;
+    bool ok;
+    SPK_DEV IBufRef operator[](long e) const { return IBufRef{r, voff, soff + (unsigned)e * stride8}; }
+    SPK_DEV IVec operator+(long off) const { return IVec{r, stride8, voff, soff + (unsigned)off * stride8, ok}; }
+    SPK_DEV explicit operator bool() const { return ok; }
+};
+SPK_DEV IVec ivec_make(const double *base_tile, long stride, int lane, long n_elems) {
+    const unsigned long bytes = ((unsigned long)(n_elems > 0 ? n_elems - 1 : 0) * (unsigned long)stride + 64ul) * 8ul;
+    return IVec{__builtin_amdgcn_make_buffer_rsrc((void *)base_tile, 0, (int)(bytes > 0xfffffffful ? 0xfffffffful : bytes), 0x00020000),
+                (unsigned)stride * 8u, (unsigned)lane * 8u, 0u, base_tile != nullptr};
+}
+SPK_DEV IVec ivec_null() { return IVec{__builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000), 0u, 0u, 0u, false}; }
+#endif
+typedef IVec ICVec;
+// LDS slots of the sweep: element e of this lane at p[e * 64]
+struct LVec {
+    double *p;
+    SPK_DEV double &operator[](long e) const { return p[e * 64]; }
+    SPK_DEV LVec operator+(long off) const { return LVec{p + off * 64}; }
+    SPK_DEV explicit operator bool() const { return p != nullptr; }
+};
+// Block fence of the element-major instantiation: the node-local bodies are one long straight-line block there, and the
+// machine scheduler, left alone, hoists every load of a node to the top (hundreds of live registers, scalar and vector).  A
+// scheduling barrier between the blocks of a phase keeps a block's loads next to its arithmetic; memory-level parallelism then
+// comes from the waves a CU holds rather than from one wave's depth.  No effect on the one-thread-per-node instantiations.
+template <class V> struct IsIlvView { static constexpr bool value = false; };
+template <> struct IsIlvView<IVec> { static constexpr bool value = true; };
+template <class V>
+SPK_DEV void spk_block_fence() {
+#ifndef SPOCK_HOST_EMU
+    if constexpr (IsIlvView<V>::value) __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// Residual maxima |xi|_inf with NaN propagation (a NaN residual must end the solve with SPOCK_NAN).  One-thread-per-node kernels:
+// a NaN-propagating compare-and-select per entry (spk_max_nan).  Element-major kernels, where the vector ALU is the scarcer
+// resource: a plain maximum (one instruction) plus one FMA per entry into a `poison` accumulator that turns NaN as soon as any
+// entry is NaN or infinite (0 * x); the workgroup's maxima are replaced by NaN when it did (spock_igroup.hpp: reduce_maxima).
+template <class V>
+SPK_DEV void spk_resmax(double &m, double x, double &poison) {
+#ifndef SPOCK_HOST_EMU
+    if constexpr (IsIlvView<V>::value) {
+        m = __builtin_fmax(m, __builtin_fabs(x));
+        poison = __builtin_fma(x, 0., poison);
+        return;
+    }
+#endif
+    m = (fabs(x) > m || x != x) ? fabs(x) : m;
+}
+
+// vbar.v2 of a node's children handed over in registers (crown chunks of the element-major fused kernel)
+template <int MAXD>
+struct V2Reg {
+    double v[MAXD];
+    int base;
+    SPK_DEV double operator[](int i) const {
+        double r = v[0];
+        for (int c = 1; c < MAXD; ++c) if (i - base == c) r = v[c];
+        return r;
+    }
+};
+SPK_DEV bool v2x_applies(const double *p, bool kids_gleaf) { return p && kids_gleaf; }
+template <int MAXD>
+SPK_DEV bool v2x_applies(const V2Reg<MAXD> &, bool) { return true; }
+
+// ------------------------------------------------------------------------------------------------
 // group geometry: thread tau <-> local BFS index tau of a complete d-ary group tree
 template <class P>
 SPK_DEV void init_geometry(const P &p, const Dims &dm, int tau, int root_stage, int root_pos, int stages, bool crown,
@@ -177,10 +274,8 @@ SPK_DEV void init_geometry(const P &p, const Dims &dm, int tau, int root_stage, 
 // ------------------------------------------------------------------------------------------------
 // phase A, node-local:  zbar0 = (-gamma) L'v + z on the entries owned by node i, then S2, then the
 // node-local terms of the S1 recursion: c_i = U_t ubar_i - xbar_i and e_i = Rt^-1 ubar_i (spock_host.cpp).
-template <class P>
-SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
-                     const double *__restrict__ v, double *__restrict__ zo, TState<P> &s, double gamma, unsigned flags,
-                     const double *v2x = nullptr) {
+template <class P, class ZI, class VI, class ZO, class V2>
+SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, TState<P> &s, double gamma, unsigned flags, V2 v2x) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu;
     const double mg = -gamma;
@@ -196,6 +291,7 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         }
         SPK_UNROLL for (int k = 0; k < nx; ++k) xbar[k] = mg * acc[k] + z[dm.zx + i * nx + k];
     }
+    spk_block_fence<ZI>();
     // u_i <- Gamma' v7 + sum_j sqrtR_j v4_j  (implicit_l.jl:399-420)
     {
         double acc[P::MAXNU];
@@ -206,6 +302,7 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         }
         SPK_UNROLL for (int k = 0; k < nu; ++k) ubar[k] = mg * acc[k] + z[dm.zu + i * nu + k];
     }
+    spk_block_fence<ZI>();
     // [y_i ; s_children ; tau_children]  (implicit_l.jl:423-448)
     double vec[P::MAXM];
     const double v2i = v[dm.o2 + i];
@@ -214,12 +311,13 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = s.c0 + c;
         double ls;
-        if (v2x && s.kids_gleaf) ls = v2x[s.pos * d + c];   // crown workgroup of the fused B+A kernel, children = subtree roots
+        if (v2x_applies(v2x, s.kids_gleaf)) ls = v2x[s.pos * d + c];   // crown workgroup of the fused B+A kernel, children = subtree roots
         else if (j < dm.nn) ls = v[dm.o2 + j];
         else ls = 0.5 * v[dm.o12 + (j - dm.nn)] + 0.5 * v[dm.o13 + (j - dm.nn)];
         vec[ny + c] = mg * ls + z[dm.zs + j];
         vec[ny + d + c] = mg * (0.5 * v[dm.o5 + j - 1] + 0.5 * v[dm.o6 + j - 1]) + z[dm.zt + j - 1];
     }
+    spk_block_fence<ZI>();
     // leaf children: x_j <- v14_j + sqrtQN v11_j  (implicit_l.jl:376-396)
     if (s.kids_leaf) {
         SPK_UNROLL for (int c = 0; c < d; ++c) {
@@ -244,6 +342,7 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
     }
     // s_1: (z - gamma L'v)[s_1] - gamma  (prox_f!, implicit_l.jl:741)
     if (i == 0) zo[dm.zs] = (mg * v[dm.o2] + z[dm.zs]) - gamma;
+    spk_block_fence<ZI>();
     // S2: projector onto ker [E' -I -I ; F' 0 0] applied to [y_i; s_ch; tau_ch]  (implicit_l.jl:708-726)
     const int m = ny + 2 * d;
     const MatPtr LS = M + dm.mLs;
@@ -254,6 +353,7 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         else if (r < ny + d) zo[dm.zs + s.c0 + (r - ny)] = t;
         else zo[dm.zt + s.c0 + (r - ny - d) - 1] = t;
     }
+    spk_block_fence<ZI>();
     // node-local terms of the S1 recursion
     const MatPtr Ut = M + dm.mU + s.stage * nx * nu;
     const MatPtr Ri = M + dm.mRinv + s.stage * nu * nu;
@@ -269,6 +369,15 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
     }
 }
 
+// plain-pointer form (instance-major layout): the restrict qualifiers tell the compiler that the iterate it reads and the
+// one it writes do not overlap, which lets it issue the loads of a phase ahead of that phase's stores
+template <class P>
+SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
+                     const double *__restrict__ v, double *__restrict__ zo, TState<P> &s, double gamma, unsigned flags,
+                     const double *v2x = nullptr) {
+    a_local_g(p, dm, M, z, v, zo, s, gamma, flags, v2x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // one level of the backward recursion (implicit_l.jl:584-637, restructured: see spock_host.cpp) for the
 // thread's node at global stage t:  q_i = c_i + sum_j W_{t,j} q_j,  d_i = e_i - sum_j V_{t,j} q_j.
@@ -277,9 +386,8 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
 //   q_out : where the group root's q goes (subtree -> global), or nullptr
 //   SW    : the sweep block of stage t ([W | V | ABK | K], spock_host.cpp) -- in LDS (const double *) or in the
 //           constant-address-space pool (MatPtr)
-template <class P, class MPT>
-SPK_DEV void bwd_node(const P &p, const Dims &dm, MPT SW, int tau, double *ex,
-                      const double *qg, double *q_out, TState<P> &s) {
+template <class P, class MPT, class EX, class QG, class QO>
+SPK_DEV void bwd_node(const P &p, const Dims &dm, MPT SW, int tau, EX ex, QG qg, QO q_out, TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
     double qi[P::MAXNX], di[P::MAXNU];
     SPK_UNROLL for (int k = 0; k < nx; ++k) qi[k] = s.xb[k];
@@ -310,9 +418,8 @@ SPK_DEV void bwd_node(const P &p, const Dims &dm, MPT SW, int tau, double *ex,
 // one level of the forward roll-out (implicit_l.jl:667-681).  xroot: x of the group root (x0 or the
 // value the crown stored).  Nothing is stored to global memory here: a store in front of the level's
 // barrier would make every level wait for its write acknowledgement; fwd_store() runs after the sweep.
-template <class P, class MPT>
-SPK_DEV void fwd_node(const P &p, const Dims &dm, MPT SW, MPT Bm, int tau, double *ex,
-                      const double *xroot, TState<P> &s) {
+template <class P, class MPT, class EX, class XR>
+SPK_DEV void fwd_node(const P &p, const Dims &dm, MPT SW, MPT Bm, int tau, EX ex, XR xroot, TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
     double xi[P::MAXNX];
     if (s.lvl == 0) { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = xroot[k]; }
@@ -339,8 +446,8 @@ SPK_DEV void fwd_node(const P &p, const Dims &dm, MPT SW, MPT Bm, int tau, doubl
 }
 
 // after the forward sweep: x_i, u_i (and the x of children that are group leaves) -> zbar
-template <class P>
-SPK_DEV void fwd_store(const P &p, const Dims &dm, double *__restrict__ zo, const TState<P> &s) {
+template <class P, class ZO>
+SPK_DEV void fwd_store(const P &p, const Dims &dm, ZO zo, const TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
     SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + s.node * nx + k] = s.xb[k];
     SPK_UNROLL for (int k = 0; k < nu; ++k) zo[dm.zu + s.node * nu + k] = s.ub[k];
@@ -493,9 +600,8 @@ struct ProxScal {
 
 // vbar.v2 of node j alone, the same arithmetic as b_local's risk block.  The fused B+A kernel's crown workgroup needs
 // it for the subtree roots, whose own threads sit in other workgroups of the same launch.
-template <class P>
-SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, const double *z, const double *v, const double *zb, int j,
-                            const ProxScal &ps) {
+template <class P, class ZI, class VI, class ZB>
+SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, int j, const ProxScal &ps) {
     const int ny = p.ny();
     const MatPtr bb = M + dm.mb;
     double bw = 0.;
@@ -521,16 +627,16 @@ SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, const double *
 // PART: 0 everything; 1 without the leaf-children blocks; 2 only the leaf-children blocks.  The leaf blocks share nothing
 // with the rest but the residual maxima and the SP sums (both reduced over the workgroup anyway), so in the single-instance
 // regime, where the workgroup has idle waves during phase B, a second thread does them at the same time (spock_group.hpp).
-template <class P, int SPM = 0, int PART = 0>
-SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
-                     const double *__restrict__ v, const double *zb, double *__restrict__ vo, TState<P> &s,
-                     const ProxScal &ps, unsigned flags, double *mx, double *sp = nullptr, const double *dirz = nullptr,
-                     const double *dirv = nullptr) {
+template <class P, int SPM, int PART, class ZI, class VI, class ZB, class VO>
+SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, VO vo, TState<P> &s,
+                       const ProxScal &ps, unsigned flags, double *mx, double *sp = nullptr, const double *dirz = nullptr,
+                       const double *dirv = nullptr) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu;
     const double sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0, wx = ps.want_xi;
     double m1 = mx[0], m2 = mx[1], m3 = mx[2];
+    double poison = IsIlvView<ZI>::value ? mx[3] : 0.;   // element-major instantiation: mx has a fourth slot (spk_resmax)
     constexpr bool MAIN = (PART != 2), LEAF = (PART != 1);
     double sp_z = 0., sp_v = 0., sp_d = 0.;
     const double gm = ps.gamma;
@@ -636,24 +742,25 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         }
         const double dv2 = nv2 - v[dm.o2 + i];
         const double x2 = (dzs - bdz) + nis * dv2;          // xi_2 on v2
-        m2 = spk_max_nan(m2, fabs(x2));
+        spk_resmax<ZI>(m2, x2, poison);
         acc_v(dm.o2 + i, dv2, x2);
         vo[dm.o2 + i] = nv2;
         SPK_UNROLL for (int k = 0; k < ny; ++k) {
             const double dv1 = pr[k] - v[i * ny + k];
             vo[i * ny + k] = pr[k];
             const double x2k = dzy[k] + nis * dv1;          // xi_2 on v1
-            m2 = spk_max_nan(m2, fabs(x2k));
+            spk_resmax<ZI>(m2, x2k, poison);
             const double x1k = (dv1 - bb[k] * dv2) + nig * dzy[k];   // xi_1 on y (implicit_l.jl:423-429)
-            m1 = spk_max_nan(m1, fabs(x1k));
+            spk_resmax<ZI>(m1, x1k, poison);
             acc_v(i * ny + k, dv1, x2k); acc_z(dm.zy + i * ny + k, dzy[k], x1k);
-            if (wx) m3 = spk_max_nan(m3, fabs((x2k - bb[k] * x2) + x1k));
+            if (wx) spk_resmax<ZI>(m3, (x2k - bb[k] * x2) + x1k, poison);
         }
         const double x1s = dv2 + nig * dzs;                 // xi_1 on s_i (implicit_l.jl:440-442)
-        m1 = spk_max_nan(m1, fabs(x1s));
+        spk_resmax<ZI>(m1, x1s, poison);
         acc_z(dm.zs + i, dzs, x1s);
-        if (wx) m3 = spk_max_nan(m3, fabs(x2 + x1s));
+        if (wx) spk_resmax<ZI>(m3, x2 + x1s, poison);
     }
+    spk_block_fence<ZI>();
     // ---- v7 : box on (x_i, u_i)  (implicit_l.jl:275-282, constraints.jl:38-54) ---------------------
     if (MAIN) {
         SPK_UNROLL for (int k = 0; k < nxu; ++k) {
@@ -671,7 +778,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
             vo[dm.o7 + i * nxu + k] = nvv;
             const double dv = nvv - vin;
             const double x2 = dzv + nis * dv;
-            m2 = spk_max_nan(m2, fabs(x2));
+            spk_resmax<ZI>(m2, x2, poison);
             acc_v(dm.o7 + i * nxu + k, dv, x2);
             if (isx) { ltx[k] = dv; lxx[k] = x2; } else { ltu[k - nx] = dv; lxu[k - nx] = x2; }
         }
@@ -679,6 +786,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
     // ---- per child j: (v6_j; v3_j, v4_j, v5_j) in SOC(nx+nu+2)  (implicit_l.jl:226-272, :854-900) ---
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = s.c0 + c, jn = j - 1;
+        spk_block_fence<ZI>();
         if (MAIN) {
         const MatPtr SQ = M + dm.mSqQ + (P::SHARED ? 0 : jn) * nx * nx;
         const MatPtr SR = M + dm.mSqR + (P::SHARED ? 0 : jn) * nu * nu;
@@ -714,7 +822,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         SPK_UNROLL for (int r = 0; r < nu; ++r) { vo[dm.o4 + jn * nu + r] = pj[1 + nx + r]; tt[1 + nx + r] = pj[1 + nx + r] - v[dm.o4 + jn * nu + r]; }
         vo[dm.o5 + jn] = pj[1 + nxu];
         tt[1 + nxu] = pj[1 + nxu] - v[dm.o5 + jn];
-        SPK_UNROLL for (int k = 0; k < len; ++k) { lz[k] = lz[k] + nis * tt[k]; m2 = spk_max_nan(m2, fabs(lz[k])); }
+        SPK_UNROLL for (int k = 0; k < len; ++k) { lz[k] = lz[k] + nis * tt[k]; spk_resmax<ZI>(m2, lz[k], poison); }
         if (SPM >= 1) {
             acc_v(dm.o6 + jn, tt[0], lz[0]);
             SPK_UNROLL for (int r = 0; r < nx; ++r) acc_v(dm.o3 + jn * nx + r, tt[1 + r], lz[1 + r]);
@@ -727,11 +835,12 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
         if (wx) { sym_mv<P, true>(nx, SQ, lz + 1, lxx); sym_mv<P, true>(nu, SR, lz + 1 + nx, lxu); }
         // xi_1 on tau_j: 0.5 dv5 + 0.5 dv6 - dtau/gamma  (implicit_l.jl:432-437)
         const double x1t = (0.5 * tt[1 + nxu] + 0.5 * tt[0]) + nig * dzt;
-        m1 = spk_max_nan(m1, fabs(x1t));
+        spk_resmax<ZI>(m1, x1t, poison);
         acc_z(dm.zt + jn, dzt, x1t);
-        if (wx) m3 = spk_max_nan(m3, fabs((0.5 * lz[1 + nxu] + 0.5 * lz[0]) + x1t));
+        if (wx) spk_resmax<ZI>(m3, (0.5 * lz[1 + nxu] + 0.5 * lz[0]) + x1t, poison);
         }
 
+        spk_block_fence<ZI>();
         // ---- leaf child: (v13; v11, v12) in SOC(nx+2), v14 in the x box (implicit_l.jl:286-317, :752-810)
         if (LEAF && s.kids_leaf) {
             const int li = j - dm.nn;
@@ -768,7 +877,7 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
             SPK_UNROLL for (int r = 0; r < nx; ++r) { vo[dm.o11 + li * nx + r] = p3[1 + r]; t3[1 + r] = p3[1 + r] - v[dm.o11 + li * nx + r]; }
             vo[dm.o12 + li] = p3[1 + nx];
             t3[1 + nx] = p3[1 + nx] - v[dm.o12 + li];
-            SPK_UNROLL for (int k = 0; k < l2; ++k) { l3[k] = l3[k] + nis * t3[k]; m2 = spk_max_nan(m2, fabs(l3[k])); }
+            SPK_UNROLL for (int k = 0; k < l2; ++k) { l3[k] = l3[k] + nis * t3[k]; spk_resmax<ZI>(m2, l3[k], poison); }
             if (SPM >= 1) {
                 acc_v(dm.o13 + li, t3[0], l3[0]);
                 SPK_UNROLL for (int r = 0; r < nx; ++r) acc_v(dm.o11 + li * nx + r, t3[1 + r], l3[1 + r]);
@@ -786,44 +895,54 @@ SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
                 vo[dm.o14 + li * nx + r] = nvv;
                 const double dv = nvv - vin;
                 const double x2 = dl[r] + nis * dv;
-                m2 = spk_max_nan(m2, fabs(x2));
+                spk_resmax<ZI>(m2, x2, poison);
                 const double x1 = (dv + a11[r]) + nig * dl[r];
-                m1 = spk_max_nan(m1, fabs(x1));
+                spk_resmax<ZI>(m1, x1, poison);
                 acc_v(dm.o14 + li * nx + r, dv, x2); acc_z(dm.zx + j * nx + r, dl[r], x1);
-                if (wx) m3 = spk_max_nan(m3, fabs((x2 + b11[r]) + x1));
+                if (wx) spk_resmax<ZI>(m3, (x2 + b11[r]) + x1, poison);
             }
             const double x1s = (0.5 * t3[1 + nx] + 0.5 * t3[0]) + nig * dzs;   // s_leaf (implicit_l.jl:445-448)
-            m1 = spk_max_nan(m1, fabs(x1s));
+            spk_resmax<ZI>(m1, x1s, poison);
             acc_z(dm.zs + j, dzs, x1s);
-            if (wx) m3 = spk_max_nan(m3, fabs((0.5 * l3[1 + nx] + 0.5 * l3[0]) + x1s));
+            if (wx) spk_resmax<ZI>(m3, (0.5 * l3[1 + nx] + 0.5 * l3[0]) + x1s, poison);
         }
     }
+    spk_block_fence<ZI>();
     // xi_1 (and xi) on x_i, u_i
     SPK_UNROLL for (int k = 0; k < (MAIN ? nx : 0); ++k) {
         const double x1 = ltx[k] + nig * dzx[k];
-        m1 = spk_max_nan(m1, fabs(x1));
+        spk_resmax<ZI>(m1, x1, poison);
         acc_z(dm.zx + i * nx + k, dzx[k], x1);
-        if (wx) m3 = spk_max_nan(m3, fabs(lxx[k] + x1));
+        if (wx) spk_resmax<ZI>(m3, lxx[k] + x1, poison);
     }
     SPK_UNROLL for (int k = 0; k < (MAIN ? nu : 0); ++k) {
         const double x1 = ltu[k] + nig * dzu[k];
-        m1 = spk_max_nan(m1, fabs(x1));
+        spk_resmax<ZI>(m1, x1, poison);
         acc_z(dm.zu + i * nu + k, dzu[k], x1);
-        if (wx) m3 = spk_max_nan(m3, fabs(lxu[k] + x1));
+        if (wx) spk_resmax<ZI>(m3, lxu[k] + x1, poison);
     }
+    if (IsIlvView<ZI>::value) mx[3] = poison;
     mx[0] = m1; mx[1] = m2; mx[2] = m3;
     if (SPM >= 1) { sp[0] += sp_z; sp[1] += sp_v; }
     if (SPM == 2) sp[2] += sp_d;
 }
 
+template <class P, int SPM = 0, int PART = 0>
+SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
+                     const double *__restrict__ v, const double *zb, double *__restrict__ vo, TState<P> &s,
+                     const ProxScal &ps, unsigned flags, double *mx, double *sp = nullptr, const double *dirz = nullptr,
+                     const double *dirv = nullptr) {
+    b_local_g<P, SPM, PART>(p, dm, M, z, v, zb, vo, s, ps, flags, mx, sp, dirz, dirv);
+}
+
 // ------------------------------------------------------------------------------------------------
 // closed-loop step (examples/server_heat/mpc_simulation.jl:164-177): u = z[u_inds[1:nu]], x0 <- A_w x0 + B_w u.
 // One thread per instance-row; `row` in [0, nx).
-SPK_DEV double mpc_advance_row(const Dims &dm, MatPtr M, const double *z, const double *x0, int w, int row) {
+SPK_DEV double mpc_advance_row(const Dims &dm, MatPtr M, const double *z, long stride_e, const double *x0, int w, int row) {
     const MatPtr A = M + dm.mA + w * dm.nx * dm.nx, B = M + dm.mB + w * dm.nx * dm.nu;
     double a = 0., b = 0.;
     for (int k = 0; k < dm.nx; ++k) a += A[row + k * dm.nx] * x0[k];
-    for (int k = 0; k < dm.nu; ++k) b += B[row + k * dm.nx] * z[dm.zu + k];
+    for (int k = 0; k < dm.nu; ++k) b += B[row + k * dm.nx] * z[(long)(dm.zu + k) * stride_e];
     return a + b;
 }
 

@@ -146,6 +146,44 @@ int choose_split_stage(int N, int d, int nx, int nu, int batch) {
     return t0;
 }
 
+// Element-major batched regime: a subtree workgroup keeps one q / x slot of nx x 64 doubles per non-leaf node in LDS; subtrees
+// of up to ~40 KB of slots leave room for three workgroups per CU.  The crown (stages <= t0) exchanges through global memory.
+int choose_split_stage_ilv(int N, int d, int nx) {
+    int S = 2;
+    while (S + 1 <= N - 1 && (long)group_threads(d, S + 1) * nx * 64 * 8 <= 40 * 1024) ++S;
+    return N - S;
+}
+
+// non-leaf levels a group of the element-major regime may span (LDS slots of nx x 64 doubles per non-leaf node, <= ~40 KB)
+static int ilv_group_span(int d, int nx) {
+    int S = 2;
+    while (S < 12 && (long)group_threads(d, S + 1) * nx * 64 * 8 <= 40 * 1024) ++S;
+    return S - 1;
+}
+
+IlvGeo ilv_geometry(int mode, const Dims &dm, int level) {
+    IlvGeo g;
+    const int d = dm.d, nx = dm.nx;
+    const int sub_nl = group_threads(d, dm.sub_stages), crown_nl = group_threads(d, dm.t0 + 1);
+    g.cchunk = sub_nl > 0 ? sub_nl : 1;
+    g.n_cchunks = (crown_nl + g.cchunk - 1) / g.cchunk;
+    int nW = 4;
+    if (const char *e = std::getenv("SPOCK_AMD_ILV_WAVES")) { nW = std::atoi(e); if (nW < 1) nW = 1; if (nW > 4) nW = 4; }
+    g.ex_doubles = 0;
+    g.threads = 64 * nW;
+    if (mode == MODE_FINALIZE) { g.threads = 64; g.grid_x = 1; }
+    else if (mode == MODE_ICROWN_A) g.grid_x = g.n_cchunks;
+    else if (mode == MODE_SUB_A || mode == MODE_SUB_BA) { g.grid_x = dm.nsub; g.ex_doubles = sub_nl * nx * 64; }
+    else {   // CROWN (top group, level 0), I_UP / I_DOWN (mid groups of `level`)
+        const int lv = mode == MODE_CROWN ? 0 : level;
+        g.grid_x = ipow(d, dm.lv_root[lv]);
+        g.ex_doubles = group_threads(d, dm.lv_root[lv + 1] - dm.lv_root[lv] + 1) * nx * 64;
+    }
+    // [exchange slots][maxima: waves x 3 x 64][64 live flags]
+    g.lds_bytes = (size_t)g.ex_doubles * 8 + (size_t)(g.threads / 64) * 3 * 64 * 8 + 64 * 4 + 64;
+    return g;
+}
+
 bool team_local_applies(const Dims &dm) {
     if (std::getenv("SPOCK_AMD_NO_TEAM_LOCAL")) return false;
     const bool big = (dm.nx > 8 || dm.nu > 8) || std::getenv("SPOCK_AMD_FORCE_TEAM_LOCAL");   // (the override is for experiments)
@@ -298,6 +336,16 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
     dm.t0 = t0;
     dm.nsub = t0 > 0 ? ipow(d, t0) : 1;
     dm.sub_stages = N - t0;
+    {   // hierarchy of groups of the element-major regime: bottom layer at t0, layers of `span` non-leaf levels above it
+        const int span = ilv_group_span(d, nx);
+        int roots[8], n = 0;
+        for (int t = t0; t > 0 && n < 7; t -= span) roots[n++] = t;   // bottom layer first
+        roots[n++] = 0;                                                // the top group starts at the tree root
+        dm.n_lv = n;
+        for (int k = 0; k < n; ++k) dm.lv_root[k] = roots[n - 1 - k];
+        dm.n_crown_groups = 0;
+        for (int k = 0; k + 1 < n; ++k) dm.n_crown_groups += ipow(d, dm.lv_root[k]);
+    }
 
     // ---- offline Riccati recursion (implicit_l.jl:46-97), per stage --------------------------------
     std::vector<Mat> A(d), B(d);

@@ -37,6 +37,8 @@ struct Dims {
     int mU, mW, mV;
     // per-stage sweep blocks (offsets inside one block, block stride, pool offset of stage 0)
     int mSweep, sw_stride, sw_oW, sw_oV, sw_oABK, sw_oK;
+    // element-major regime: hierarchy of groups (spock_igroup.hpp): root stages of the layers, top (0) first, bottom (t0) last
+    int n_lv, lv_root[8], n_crown_groups;
     int mA;          // A_w, d matrices (closed-loop state update of the MPC loop)
     int diag_costs;  // every sqrtQ / sqrtR / sqrtQN is diagonal -> element-wise products in the kernels
 };
@@ -105,6 +107,15 @@ struct KArgs {
     int team;                   // > 0: lane-team sweeps with this many lanes per node (all sweep vectors in LDS)
     double *xlbuf;              // [batch][groups][xl_stride]: the group-leaf sweep vector when it does not fit in LDS
     int xl_global, xl_stride;
+    // element-major ("interleaved") batched regime (spock_igroup.hpp): every per-instance array is [element][bp], bp = batch
+    // rounded up to a multiple of 64; one wave = one tree node x one tile of 64 instances
+    int ilv;
+    long bp;
+    double *cq;                 // [crown non-leaf nodes][nx][bp]: q / x exchange of the crown's sweep (global memory)
+    int cchunk, n_cchunks;      // crown nodes per workgroup of the node-local crown phases, number of such workgroups
+    int want_xi;                // element-major regime: LOG-mode CP (combined residual xi, cp.jl:83-86) selects the kernel variant
+    int grp_level;              // element-major regime, I_UP / I_DOWN: the layer of mid groups this launch works on
+    int tile0, n_tiles;         // element-major regime: the launch covers tiles tile0 .. tile0 + n_tiles - 1 (n_tiles 0 = all)
 };
 
 // ---- SP (SuperMann + Anderson) driver: plain data shared by the kernels (spock_sp.hpp) and the driver ----
@@ -152,7 +163,9 @@ enum SpOp { SP_FLAT1 = 1, SP_FLAT2, SP_FLAT3, SP_FLAT4, SP_FLAT5, SP_LOP_R, SP_L
 enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, MODE_FINALIZE = 4, MODE_SUB_BA = 5,
                  MODE_SUB_B_SP = 6, MODE_FULL_SP = 7,
                  MODE_SUB_B_LAT = 8,   // SUB_B of the single-instance regime: the leaf-children blocks of phase B on an idle wave
-                 N_GROUP_MODES = 9 };
+                 N_GROUP_MODES = 9,
+                 // element-major regime only (spock_igroup.hpp): the node-local phases of the crown's nodes, chunked over workgroups
+                 MODE_ICROWN_A = 9, MODE_I_UP = 10, MODE_I_DOWN = 11 };
 
 // ---- host build step (spock_host.cpp) -------------------------------------------------------------
 struct HostProblem {
@@ -180,22 +193,32 @@ bool team_local_applies(const Dims &dm);   // lane-team node-local phases: large
 LaunchGeo launch_geometry(int mode, const Dims &dm, int batch);
 int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tree with `stages` stages
 
+// element-major batched regime: split stage (subtrees of at most `max_sub_stages` stages, LDS-bound), launch geometry
+int choose_split_stage_ilv(int N, int d, int nx);
+struct IlvGeo { int threads, grid_x, cchunk, n_cchunks; size_t lds_bytes; int ex_doubles; };
+IlvGeo ilv_geometry(int mode, const Dims &dm, int level = 0);
+
 // ---- kernel launchers (spock_kernels.hip) ---------------------------------------------------------
 // Each returns a hipError_t cast to int.  `stream` is a hipStream_t.
 int launch_group(int mode, const KArgs &a, void *stream);
+int launch_igroup(int mode, const KArgs &a, void *stream);   // element-major batched regime (a.ilv), spock_ikernels.hip
 bool have_static_variant(int nx, int nu, int d, int ny);
 // closed-loop step of examples/server_heat/mpc_simulation.jl:164-177 on the device
 struct MpcArgs {
     Dims dm;
     const double *mats;
-    const double *z;        // iterate of instance b at z + b * stride_z (the u block of node 0 is the applied input)
-    long stride_z;
+    const double *z;        // element e of instance b at z[b * stride_z + e * stride_e] (the u block of node 0 is the applied input)
+    long stride_z, stride_e;
     double *x0;             // [batch][nx], updated in place: x0 <- A_w x0 + B_w u
     const int *w_seq;       // [batch][steps] events
     double *x_traj, *u_traj;  // [batch][steps+1][nx], [batch][steps][nu]
     int t, steps, batch;
 };
 int launch_mpc_advance(const MpcArgs &a, void *stream);
+// dst[c * ld_dst + r] = src[r * ld_src + c] for r < rows, c < cols (instance-major <-> element-major copies of the state)
+int launch_transpose(double *dst, const double *src, long rows, long cols, long ld_src, long ld_dst, void *stream);
+// element-major state: column b of z0 / v0 <- column b of the buffer its control block's result_parity names
+int launch_ilv_collect(double *const *z3, double *const *v2, const Ctl *ctl, long nz, long nv, long bp, int batch, void *stream);
 int launch_sp(const SpArgs &a, void *stream);   // a.op selects the kernel (spock_sp.hpp)
 int sp_flat_blocks(long nr);                    // workgroups per instance of the flat kernels
 int sp_lop_blocks(const Dims &dm);              // workgroups per instance of the LOP kernels

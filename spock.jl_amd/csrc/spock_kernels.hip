@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "spock_group.hpp"
+#include "spock_shapes.hpp"
 #include "spock_sp.hpp"
 #include "spock_team_local.hpp"
 
@@ -153,10 +154,7 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// compile-time shapes: (nx, nu, d, ny)
-#ifndef SPOCK_STATIC_SHAPES   // (experiment builds narrow the list: tools/build_variant.py)
-#define SPOCK_STATIC_SHAPES(X) X(5, 2, 2, 5) X(5, 5, 2, 5) X(2, 1, 2, 5) X(3, 2, 3, 7)
-#endif
+
 
 bool have_static_variant(int nx, int nu, int d, int ny) {
 #define X(a, b, c, e) if (nx == a && nu == b && d == c && ny == e) return true;
@@ -170,6 +168,7 @@ int launch_group(int mode, const KArgs &a, void *stream) {
     const Dims &dm = a.dm;
     const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
     static const bool force_dyn = std::getenv("SPOCK_AMD_FORCE_DYN") != nullptr;   // experiments: run-time-dimension kernels for every shape
+    if (a.ilv) return launch_igroup(mode, a, stream);   // element-major batched regime (spock_ikernels.hip)
 #define X(a_, b_, c_, e_)                                                                      \
     if (!force_dyn && dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                  \
         return cm == 2 ? launch_variant<StaticDims<a_, b_, c_, e_, 2>>(mode, a, st) : cm == 1 ? launch_variant<StaticDims<a_, b_, c_, e_, 1>>(mode, a, st)    \
@@ -346,9 +345,9 @@ __global__ void __launch_bounds__(64) spock_mpc_advance_kernel(const MpcArgs a) 
     double xn = 0.;
     if (r < dm.nx) {
         if (a.t == 0) a.x_traj[((long)inst * (a.steps + 1)) * dm.nx + r] = x0[r];
-        xn = mpc_advance_row(dm, (MatPtr)a.mats, z, x0, w, r);
+        xn = mpc_advance_row(dm, (MatPtr)a.mats, z, a.stride_e, x0, w, r);
     }
-    if (r < dm.nu) a.u_traj[((long)inst * a.steps + a.t) * dm.nu + r] = z[dm.zu + r];
+    if (r < dm.nu) a.u_traj[((long)inst * a.steps + a.t) * dm.nu + r] = z[(long)(dm.zu + r) * a.stride_e];
     __syncthreads();   // every row has read the old x0
     if (r < dm.nx) { x0[r] = xn; a.x_traj[((long)inst * (a.steps + 1) + a.t + 1) * dm.nx + r] = xn; }
 }

@@ -20,6 +20,7 @@ int sync(void *s);
 int event_create(void **e);
 int event_destroy(void *e);
 int event_record(void *e, void *s);
+int stream_wait_event(void *s, void *e);   // later work of stream s waits for the work recorded in e (also inside a capture: fork / join)
 int event_elapsed(float *ms, void *e0, void *e1);
 bool timing_supported();   // events measure device time (false in the host emulation)
 // stream capture of a launch sequence into an executable graph

@@ -20,6 +20,7 @@ int sync(void *s) { RT(hipStreamSynchronize((hipStream_t)s)); }
 int event_create(void **e) { hipEvent_t ev; hipError_t r = hipEventCreate(&ev); *e = (void *)ev; RT(r); }
 int event_destroy(void *e) { RT(hipEventDestroy((hipEvent_t)e)); }
 int event_record(void *e, void *s) { RT(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); }
+int stream_wait_event(void *s, void *e) { RT(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0)); }
 int event_elapsed(float *ms, void *e0, void *e1) { RT(hipEventElapsedTime(ms, (hipEvent_t)e0, (hipEvent_t)e1)); }
 bool graphs_supported() { return true; }
 bool timing_supported() { return true; }

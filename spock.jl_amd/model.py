@@ -96,7 +96,7 @@ class Model:
 
     def __init__(self, flat: FlatProblem, options: SolverOptions, batch: int = 1, device: int = 0,
                  L_norm: float | str | None = None, max_iter: int = 0, split_stage: int = 0, graph_iters: int = 0,
-                 lib_path: str | None = None):
+                 lib_path: str | None = None, layout: str | int | None = None):
         self._lib = _lib.load_library(lib_path)
         self.problem_definition = flat
         self.options = options
@@ -105,8 +105,10 @@ class Model:
                           flat.nQ, flat.nR, flat.nQN, _ptr(flat.Q), _ptr(flat.R), _ptr(flat.QN),
                           _ptr(flat.E), _ptr(flat.F), _ptr(flat.b), len(flat.cone_kind), _ptr(flat.cone_kind),
                           _ptr(flat.cone_dim), flat.x_min, flat.x_max, flat.u_min, flat.u_max)
+        lay = {None: 0, "auto": 0, "instance": 1, "instance-major": 1, "interleaved": 2, "element-major": 2}.get(layout, layout)
         op = _lib.Options(int(options.algorithm), int(device), self.batch, int(split_stage),
-                          float("nan") if L_norm is None else (-1.0 if L_norm == "auto" else float(L_norm)), int(max_iter), int(graph_iters))
+                          float("nan") if L_norm is None else (-1.0 if L_norm == "auto" else float(L_norm)), int(max_iter), int(graph_iters),
+                          int(lay))
         h = C.c_void_p()
         _lib.check(self._lib, self._lib.spock_create(C.byref(pr), C.byref(op), C.byref(h)))
         self._h = h
@@ -217,7 +219,8 @@ class Model:
 
 def build_model(scen_tree, cost, dynamics, rms, constraints, solver_options: SolverOptions = SolverOptions(CP, None),
                 **kw) -> Model:
-    """model.jl:273-297.  Keyword extensions: batch, device, L_norm, max_iter, split_stage, graph_iters, lib_path."""
+    """model.jl:273-297.  Keyword extensions: batch, device, L_norm, max_iter, split_stage, graph_iters, lib_path, layout
+    ("instance" / "interleaved": how the batch is laid out in HBM; default: interleaved from 64 instances on)."""
     if solver_options.algorithm not in (AlgorithmOptions.CP, AlgorithmOptions.SP):
         raise ValueError("This combination of solver options is not supported.")
     return Model(flatten_problem(scen_tree, cost, dynamics, rms, constraints), solver_options, **kw)

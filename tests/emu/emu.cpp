@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../spock.jl_amd/csrc/spock_group.hpp"
+#include "../../spock.jl_amd/csrc/spock_igroup.hpp"
 #include "../../spock.jl_amd/csrc/spock_sp.hpp"
 #include "../../spock.jl_amd/csrc/spock_team_local.hpp"
 #include "../../spock.jl_amd/csrc/spock_rt.hpp"
@@ -101,6 +102,72 @@ static int launch_variant(int mode, const KArgs &a_in) {
     return 0;
 }
 
+
+// ---- element-major batched regime, emulated: the "threads" of a workgroup run one after the other between barriers -------
+template <class P>
+struct EmuIExec {
+    std::vector<IState<P>> st;
+    std::vector<double> ex, rd;
+    int lf[64] = {0};
+    int nthreads_v;
+    bool reverse;
+    EmuIExec(int thr, int ex_doubles) : st(thr), ex((size_t)ex_doubles + 8, 0.), rd((size_t)(thr / 64) * 3 * 64 + 8, 0.), nthreads_v(thr), reverse(env_on("SPOCK_EMU_REVERSE")) {}
+    template <class F>
+    void each(F &&f) {
+        if (!reverse) for (int t = 0; t < nthreads_v; ++t) f(t, st[t]);
+        else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t]);
+    }
+    void barrier() {}
+    double *lds() { return ex.data(); }
+    double *red() { return rd.data(); }
+    int *live_flags() { return lf; }
+    int nthreads() const { return nthreads_v; }
+};
+
+template <class P, int MODE, bool WX = false>
+static void run_iblocks(const KArgs &a, int gx, int thr) {
+    const bool rev = env_on("SPOCK_EMU_REVERSE_BLOCKS");
+    const int t_lo = a.n_tiles > 0 ? a.tile0 : 0, t_hi = a.n_tiles > 0 ? a.tile0 + a.n_tiles : (int)(a.bp / 64);
+    for (int tile = t_lo; tile < t_hi; ++tile)
+        for (int gi = 0; gi < gx; ++gi) {
+            const int g = rev ? gx - 1 - gi : gi;
+            EmuIExec<P> x(thr, a.ex_doubles);
+            igroup_body<P, MODE, WX>(x, a, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next, tile, g);
+        }
+}
+
+template <class P>
+static int launch_ivariant(int mode, const KArgs &a_in) {
+    KArgs a = a_in;
+    const IlvGeo g = ilv_geometry(mode, a.dm, a.grp_level);
+    a.ex_doubles = g.ex_doubles; a.cchunk = g.cchunk; a.n_cchunks = g.n_cchunks;
+    switch (mode) {
+        case MODE_SUB_A: run_iblocks<P, MODE_SUB_A>(a, g.grid_x, g.threads); break;
+        case MODE_CROWN: if (a.want_xi) run_iblocks<P, MODE_CROWN, true>(a, g.grid_x, g.threads); else run_iblocks<P, MODE_CROWN>(a, g.grid_x, g.threads); break;
+        case MODE_I_UP: run_iblocks<P, MODE_I_UP>(a, g.grid_x, g.threads); break;
+        case MODE_ICROWN_A: run_iblocks<P, MODE_ICROWN_A>(a, g.grid_x, g.threads); break;
+        case MODE_SUB_BA: if (a.want_xi) run_iblocks<P, MODE_SUB_BA, true>(a, g.grid_x, g.threads); else run_iblocks<P, MODE_SUB_BA>(a, g.grid_x, g.threads); break;
+        case MODE_I_DOWN: if (a.want_xi) run_iblocks<P, MODE_I_DOWN, true>(a, g.grid_x, g.threads); else run_iblocks<P, MODE_I_DOWN>(a, g.grid_x, g.threads); break;
+        case MODE_FINALIZE: run_iblocks<P, MODE_FINALIZE>(a, g.grid_x, g.threads); break;
+        default: return 1;
+    }
+    return 0;
+}
+
+int launch_transpose(double *dst, const double *src, long rows, long cols, long ld_src, long ld_dst, void *) {
+    for (long r = 0; r < rows; ++r) for (long c = 0; c < cols; ++c) dst[c * ld_dst + r] = src[r * ld_src + c];
+    return 0;
+}
+
+int launch_ilv_collect(double *const *z3, double *const *v2, const Ctl *ctl, long nz, long nv, long bp, int batch, void *) {
+    for (int b = 0; b < batch; ++b) {
+        const int rp = ctl[b].result_parity;
+        if (rp % 3) for (long e = 0; e < nz; ++e) z3[0][e * bp + b] = z3[rp % 3][e * bp + b];
+        if (rp % 2) for (long e = 0; e < nv; ++e) v2[0][e * bp + b] = v2[1][e * bp + b];
+    }
+    return 0;
+}
+
 #define SPOCK_STATIC_SHAPES(X) X(5, 2, 2, 5) X(5, 5, 2, 5) X(2, 1, 2, 5) X(3, 2, 3, 7)
 
 bool have_static_variant(int nx, int nu, int d, int ny) {
@@ -113,6 +180,14 @@ bool have_static_variant(int nx, int nu, int d, int ny) {
 int launch_group(int mode, const KArgs &a, void *) {
     const Dims &dm = a.dm;
     const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
+    if (a.ilv) {
+#define X(a_, b_, c_, e_)                                                                  \
+    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                            \
+        return cm == 2 ? launch_ivariant<StaticDims<a_, b_, c_, e_, 2>>(mode, a) : cm == 1 ? launch_ivariant<StaticDims<a_, b_, c_, e_, 1>>(mode, a) : 9;
+        SPOCK_STATIC_SHAPES(X)
+#undef X
+        return 9;
+    }
     if (!env_on("SPOCK_EMU_FORCE_DYN")) {
 #define X(a_, b_, c_, e_)                                                                  \
     if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                            \
@@ -245,9 +320,9 @@ int launch_mpc_advance(const MpcArgs &a, void *) {
         std::vector<double> xn(dm.nx);
         for (int r = 0; r < dm.nx; ++r) {
             if (a.t == 0) a.x_traj[((long)inst * (a.steps + 1)) * dm.nx + r] = x0[r];
-            xn[r] = mpc_advance_row(dm, (MatPtr)a.mats, z, x0, w, r);
+            xn[r] = mpc_advance_row(dm, (MatPtr)a.mats, z, a.stride_e, x0, w, r);
         }
-        for (int r = 0; r < dm.nu; ++r) a.u_traj[((long)inst * a.steps + a.t) * dm.nu + r] = z[dm.zu + r];
+        for (int r = 0; r < dm.nu; ++r) a.u_traj[((long)inst * a.steps + a.t) * dm.nu + r] = z[(long)(dm.zu + r) * a.stride_e];
         for (int r = 0; r < dm.nx; ++r) { x0[r] = xn[r]; a.x_traj[((long)inst * (a.steps + 1) + a.t + 1) * dm.nx + r] = xn[r]; }
     }
     return 0;
@@ -269,6 +344,7 @@ int sync(void *) { return 0; }
 struct Ev { std::chrono::steady_clock::time_point t; };
 int event_create(void **e) { *e = new Ev(); return 0; }
 int event_destroy(void *e) { delete (Ev *)e; return 0; }
+int stream_wait_event(void *, void *) { return 0; }
 int event_record(void *e, void *) { ((Ev *)e)->t = std::chrono::steady_clock::now(); return 0; }
 int event_elapsed(float *ms, void *e0, void *e1) {
     *ms = std::chrono::duration<float, std::milli>(((Ev *)e1)->t - ((Ev *)e0)->t).count();

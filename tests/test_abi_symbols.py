@@ -32,7 +32,7 @@ def test_library_exports_every_symbol(S, built):
     lib = S.load_library()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.spock_version() == 100
+    assert lib.spock_version() == 200
 
 
 def test_no_cpu_fallback(S, built):

@@ -423,3 +423,83 @@ def test_unsupported_inputs(S, emu):
     bad.anc = bad.anc.copy(); bad.anc[5] = 1
     with pytest.raises(S.SpockError):
         S.build_model(bad, cost, dyn, rms, con, lib_path=emu)
+
+
+# ---- element-major ("interleaved") batched regime: one lane per instance, one wave per tree node (spock_igroup.hpp) -----------
+@pytest.mark.parametrize("N,nu,B,kw", [(5, 5, 3, {}), (7, 2, 3, {}), (7, 5, 66, {}), (8, 2, 4, {"split_stage": 5}),
+                                       (10, 5, 2, {"split_stage": 8})])
+def test_emulated_interleaved_layout_matches_oracle(S, O, emu, monkeypatch, N, nu, B, kw):
+    """The element-major kernels against the oracle: different instances stop at different iterations (finished lanes freeze),
+    partial tiles (B not a multiple of 64), two tiles, one / two / three layers of groups (split 5 of N = 8: layers [0, 1, 5];
+    split 8 of N = 10: [0, 4, 8]), tile groups on separate streams, warm start, LOG-mode kernel variant, set_state / reset."""
+    monkeypatch.setenv("SPOCK_AMD_ILV_TGROUPS", "2")
+    specs = S.get_server_heat_specs(N, 5, 2, nu=nu)
+    flat = S.flatten_problem(*specs)
+    cap = 80 if N >= 8 else (300 if nu == 2 else 1200)
+    x0 = 0.1 * (1 + 0.1 * np.arange(B))[:, None] * np.ones((B, 5)); x0[B // 2] = [-0.1, 0.1, 0.05, 0.0, 0.3]
+    m = S.build_model(*specs, lib_path=emu, batch=B, layout="interleaved", max_iter=cap, **kw)
+    assert m.sizes.interleaved == 1
+    rs = S.solve_model(m, x0, tol=1e-3)
+    Z = m.solver_state.z.reshape(B, -1).copy(); V = m.solver_state.v.reshape(B, -1).copy()
+    picks = sorted(set([0, B // 2, B - 1]))
+    for b in picks:
+        o = O.Oracle(flat, O.CP); ro = o.solve(x0[b], tol=1e-3, max_iter=cap)
+        assert (rs[b]["iterations"], rs[b]["status"]) == (ro["iterations"], ro["status"])
+        assert relerr(Z[b], o.z) <= 1e-9 and relerr(V[b], o.v) <= 1e-9
+    if N <= 7 and nu == 5:      # (the nu = 2 < nx extension is infeasible: no instance converges)
+        assert len(set(r["iterations"] for r in rs)) > 1        # the instances did stop at different iterations
+    # warm start from the state left in the model, LOG-mode termination rule and residual log
+    rs2 = S.solve_model(m, 0.9 * x0, tol=1e-3, verbose=S.LOG)
+    o = O.Oracle(flat, O.CP); o.solve(x0[0], tol=1e-3, max_iter=cap)
+    ro2 = o.solve(0.9 * x0[0], tol=1e-3, verbose=O.LOG, max_iter=cap, history=cap + 2)
+    h = m.history(0)
+    assert rs2[0]["iterations"] == ro2["iterations"] and len(h["xi"]) == len(ro2["hist_xi"])
+    assert np.max(np.abs(h["xi"] - ro2["hist_xi"]) / ro2["hist_xi"]) <= 1e-8
+    assert relerr(m.solver_state.z.reshape(B, -1)[0], o.z) <= 1e-9
+    # set_state / z0, v0 / reset cross the boundary instance-major
+    m.set_state(Z, V)
+    assert np.array_equal(m.solver_state.z.reshape(B, -1), Z) and np.array_equal(m.solver_state.v.reshape(B, -1), V)
+    rs3 = S.solve_model(m, x0, tol=1e-3, z0=np.zeros_like(Z), v0=np.zeros_like(V))
+    assert [r["iterations"] for r in rs3] == [r["iterations"] for r in rs]
+    assert np.array_equal(m.solver_state.z.reshape(B, -1), Z)     # bitwise repeatable
+    m.reset()
+    assert not m.solver_state.z.any()
+    m.close()
+
+
+def test_emulated_interleaved_equals_instance_major_and_mpc(S, O, emu):
+    """Same problem, both layouts: identical iteration counts and iterates to rounding; the closed loop on the device works on
+    either layout (spock_mpc_simulate reads u_0 with the layout's stride)."""
+    specs = S.get_server_heat_specs(6, 5, 2)
+    B = 5
+    x0 = 0.1 * (1 + 0.2 * np.arange(B))[:, None] * np.ones((B, 5))
+    w = np.random.default_rng(1).integers(0, 2, size=(B, 4))
+    out = {}
+    for lay in ("instance", "interleaved"):
+        m = S.build_model(*specs, lib_path=emu, batch=B, layout=lay)
+        assert m.sizes.interleaved == (1 if lay == "interleaved" else 0)
+        xt, ut, res = S.mpc_simulation(m, x0, w, tol=1e-3)
+        out[lay] = (xt, ut, [[r["iterations"] for r in rr] for rr in res], m.solver_state.z.copy())
+        m.close()
+    assert out["instance"][2] == out["interleaved"][2]
+    assert np.max(np.abs(out["instance"][0] - out["interleaved"][0])) <= 1e-10
+    assert np.max(np.abs(out["instance"][1] - out["interleaved"][1])) <= 1e-10
+    assert relerr(out["interleaved"][3], out["instance"][3]) <= 1e-10
+
+
+def test_interleaved_layout_falls_back_or_refuses(S, emu):
+    specs = S.get_server_heat_specs(5, 5, 2)
+    # SP has no element-major kernels: chosen automatically it falls back, asked for explicitly it is refused
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, batch=70)
+    assert m.sizes.interleaved == 0
+    m.close()
+    with pytest.raises(S.SpockError):
+        S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, batch=70, layout="interleaved")
+    # run-time shapes (no compile-time variant) likewise
+    specs2 = S.get_server_heat_specs(4, 4, 3, p_ref=[0.2, 0.3, 0.5])
+    m = S.build_model(*specs2, lib_path=emu, batch=64)
+    assert m.sizes.interleaved == 0
+    m.close()
+    m = S.build_model(*specs, lib_path=emu, batch=64)      # CP, compile-time shape, >= 64 instances: element-major by default
+    assert m.sizes.interleaved == 1
+    m.close()

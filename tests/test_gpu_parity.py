@@ -398,3 +398,56 @@ def test_sp_batch_matches_single_and_lop_sequence(S, O, monkeypatch):
     assert np.max(np.abs(hb[0]["xi1"][:n] - hl["xi1"][:n]) / hl["xi1"][:n]) <= 1e-8
     assert np.max(np.abs(hb[0]["xi1"][:n] - ro["hist_xi1"][:n]) / ro["hist_xi1"][:n]) <= 1e-8
     assert np.array_equal(hb[0]["backtrack"][:n], ro["hist_backtrack"][:n])
+
+
+# ---- element-major ("interleaved") batched regime (spock_igroup.hpp): one lane per instance, one wave per tree node -----------
+@pytest.mark.parametrize("N,nu,B,kw", [(7, 5, 70, {}), (8, 2, 64, {"split_stage": 5}), (10, 5, 130, {})])
+def test_interleaved_layout_matches_oracle(S, O, N, nu, B, kw):
+    """Element-major kernels on the GPU against the oracle: partial tiles, several tiles, instances that stop at different
+    iterations, warm start + LOG-mode kernel variant, bitwise repeatability."""
+    specs = S.get_server_heat_specs(N, 5, 2, nu=nu)
+    flat = S.flatten_problem(*specs)
+    cap = 120 if N >= 8 else 1200
+    x0 = 0.1 * (1 + 0.02 * np.arange(B))[:, None] * np.ones((B, 5)); x0[B // 2] = [-0.1, 0.1, 0.05, 0.0, 0.3]
+    m = S.build_model(*specs, batch=B, max_iter=cap, **kw)
+    assert m.sizes.interleaved == 1                              # >= 64 instances, CP, compile-time shape: chosen by default
+    rs = S.solve_model(m, x0, tol=1e-3)
+    Z = m.solver_state.z.copy(); V = m.solver_state.v.copy()
+    for b in sorted(set([0, 1, B // 2, 63, 64 if B > 64 else 0, B - 1])):
+        o = O.Oracle(flat, O.CP); ro = o.solve(x0[b], tol=1e-3, max_iter=cap)
+        assert (rs[b]["iterations"], rs[b]["status"]) == (ro["iterations"], ro["status"])
+        assert relerr(Z[b], o.z) <= 1e-9 and relerr(V[b], o.v) <= 1e-9
+    rs2 = S.solve_model(m, 0.9 * x0, tol=1e-3, verbose=S.LOG)
+    o = O.Oracle(flat, O.CP); o.solve(x0[0], tol=1e-3, max_iter=cap)
+    ro2 = o.solve(0.9 * x0[0], tol=1e-3, verbose=O.LOG, max_iter=cap, history=cap + 2)
+    h = m.history(0)
+    assert rs2[0]["iterations"] == ro2["iterations"] and len(h["xi"]) == len(ro2["hist_xi"])
+    assert np.max(np.abs(h["xi"] - ro2["hist_xi"]) / ro2["hist_xi"]) <= 1e-8
+    m.reset()
+    rs3 = S.solve_model(m, x0, tol=1e-3)
+    assert [r["iterations"] for r in rs3] == [r["iterations"] for r in rs]
+    assert np.array_equal(m.solver_state.z, Z) and np.array_equal(m.solver_state.v, V)     # bitwise repeatable
+    m.close()
+
+
+def test_interleaved_full_size_cfg2(S, O):
+    """BASELINE config 2 at full size in the benchmark's regime (element-major, 3 layers of groups, 4 tile groups on their own
+    streams): 48 CP iterations of 256 instances, three of them against the oracle; NaN input ends one instance with SPOCK_NAN
+    and leaves its tile neighbours untouched."""
+    specs = S.get_server_heat_specs(13, 5, 2, nu=2)
+    flat = S.flatten_problem(*specs)
+    B = 256
+    x0 = 0.1 * (1.0 + 0.001 * np.arange(B))[:, None] * np.ones((B, 5))
+    m = S.build_model(*specs, batch=B, max_iter=48, graph_iters=48)
+    assert m.sizes.interleaved == 1 and m.sizes.fused_iteration == 1
+    rs = S.solve_model(m, x0, tol=0.0)
+    Z = m.solver_state.z
+    for b in (0, 100, 255):
+        o = O.Oracle(flat, O.CP); o.solve(x0[b], tol=0.0, max_iter=48)
+        assert rs[b]["iterations"] == 48 and relerr(Z[b], o.z) <= 1e-9 and relerr(m.solver_state.v[b], o.v) <= 1e-9
+    m.reset()
+    xb = x0.copy(); xb[70, 2] = np.nan
+    rs = S.solve_model(m, xb, tol=0.0)
+    assert rs[70]["status"] == 2 and rs[69]["status"] == 1 and rs[71]["status"] == 1
+    assert relerr(m.solver_state.z[69], Z[69]) == 0.0 and relerr(m.solver_state.z[71], Z[71]) == 0.0
+    m.close()

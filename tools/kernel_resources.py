@@ -9,7 +9,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def main():
-    obj = os.path.join(ROOT, "spock.jl_amd", "build", "spock_kernels.hip.o")
+    obj = os.path.join(ROOT, "spock.jl_amd", "build", os.environ.get("KOBJ", "spock_kernels.hip.o"))
     d = tempfile.mkdtemp()
     fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
     subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj])
