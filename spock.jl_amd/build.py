@@ -39,13 +39,17 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, out: str | None = None, tmp_name: str = "build") -> str:
+    global OUT
+    if out:
+        OUT = out
     if not force and not needs_build():
         return OUT
     objs = []
-    tmp = os.path.join(HERE, "build")
+    tmp = os.path.join(HERE, tmp_name)
     os.makedirs(tmp, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable", "-Wno-cuda-compat"]
+    flags += os.environ.get("SPOCK_BUILD_DEFS", "").split()      # experiment builds (tools/): extra -D... flags
     def compile_one(s):
         o = os.path.join(tmp, s + ".o")
         cmd = [_hipcc()] + flags + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]

@@ -518,6 +518,137 @@ SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
 }
 
 // ------------------------------------------------------------------------------------------------
+// MFMA sweeps (gfx950 only; BASELINE config 5: nx = 64, nu = 16).  With the matrices shared by all nodes of a stage, one tree
+// level of the sweep is a matrix product with the level's nodes as columns:
+//   backward   [q_i ; d_i] (+)= [W_0 W_1 ; -V_0 -V_1] (80 x 128)  x  [q_child0 ; q_child1] (128 x cnt)
+//   forward    x_child_c     =  [ABK_c  B_c]          (64 x 80)   x  [x_i ; d_i]           (80 x cnt),   u_i = K x_i + d_i
+// evaluated with v_mfma_f64_16x16x4_f64 on 16 x 16 output tiles (16 matrix rows x 16 nodes), one wave per tile, the vectors
+// in the same LDS arrays as the lane-team sweep (TeamLds), the matrix fragments straight from L2 (a stage's matrices are 155 KB).
+// Fragment maps (cdna_hip_programming.md section 3): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// C / D: column j = lane & 15, rows (lane >> 4) + 4 * reg.  A tile of a narrow level (cnt < 16) runs with its surplus columns
+// zeroed and not written back.  The f64 MFMA rate equals the vector FMA rate on MI355X (78.6 TFLOP/s); what it buys is operand
+// traffic: one 8-byte matrix element and one 8-byte vector element per lane feed 2048 flops, against one of each per FMA.
+// Rounding: the order of summation over k differs from the scalar sweeps (parity is checked at 1e-12 relative).
+#ifndef SPOCK_HOST_EMU
+typedef double spk_v4d __attribute__((ext_vector_type(4)));
+
+// instantiated shapes (nx, nu): BASELINE config 5
+SPK_DEV bool mfma_sweep_applies(int nx, int nu, int d) { return nx == 64 && nu == 16 && d == 2; }
+
+// One wave owns a ROW tile m of the level's product and keeps its matrix fragments (KF k-steps: one 8-byte element per lane
+// each) in registers while it runs over the level's node tiles: the fragments are fetched from L2 once per level and wave --
+// their latency (the sweep is a chain of small dependent levels) is paid once, not per node tile.
+template <int KF, class MPT>
+SPK_DEV void mfma_load_frags(double (&af)[KF], MPT Mx, long ld, int kq, int nk4, int k_base) {
+#pragma unroll
+    for (int q = 0; q < KF; ++q) af[q] = (q < nk4) ? Mx[(long)(k_base + 4 * q + kq) * ld] : 0.;
+}
+
+// NXC / NUC / DC: compile-time nx / nu / d of the instantiation (64 / 16 / 2 for BASELINE config 5).  Work item = (row tile m,
+// share sp of the node tiles): the wave keeps the fragments of BOTH children's matrices for its row tile and sums over the
+// children in a fixed order, so the result does not depend on which wave ran when (bitwise repeatable).
+template <int NXC, int NUC, int DC, class P, class MPT>
+SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, int cnt, bool kids_gleaf, int tid, int nthreads,
+                            const TeamLds &L) {
+    constexpr int nx = NXC, nu = NUC, d = DC, KQ = NXC / 4;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    constexpr int mq = nx / 16, mt = mq + nu / 16;
+    const int ntile = (cnt + 15) / 16;
+    int nsplit = nwaves / mt;
+    if (nsplit > ntile) nsplit = ntile;
+    if (nsplit < 1) nsplit = 1;
+    for (int it = wave; it < mt * nsplit; it += nwaves) {
+        const int m = it % mt, sp = it / mt;
+        const bool isq = m < mq;
+        const int row0 = isq ? m * 16 : (m - mq) * 16, ld = isq ? nx : nu;
+        double af[DC][KQ];
+#pragma unroll
+        for (int c = 0; c < d; ++c)
+            mfma_load_frags<KQ>(af[c], (isq ? SW + dm.sw_oW + c * nx * nx : SW + dm.sw_oV + c * nu * nx) + (row0 + j), ld, kq, KQ, 0);
+        for (int nt = sp; nt < ntile; nt += nsplit) {
+            const int pos = nt * 16 + j;
+            const bool valid = pos < cnt;
+            const int li = lvl_first + (valid ? pos : 0), posv = valid ? pos : 0;
+            spk_v4d acc = {0., 0., 0., 0.};
+#pragma unroll
+            for (int c = 0; c < d; ++c) {
+                const double *qc = kids_gleaf ? L.XL + (long)(posv * d + c) * nx : L.XQ + (long)(li * d + 1 + c) * nx;
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    const double bv = valid ? qc[4 * q + kq] : 0.;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][q], bv, acc, 0, 0, 0);
+                }
+            }
+            if (valid) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = row0 + kq + 4 * reg;
+                    if (isq) L.XQ[(long)li * nx + r] += acc[reg];
+                    else L.ED[(long)li * nu + r] -= acc[reg];
+                }
+            }
+        }
+    }
+}
+
+template <int NXC, int NUC, int DC, class P, class MPT>
+SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_first, int cnt, bool kids_gleaf, int tid, int nthreads,
+                            const TeamLds &L) {
+    constexpr int nx = NXC, nu = NUC, d = DC, KQ = NXC / 4, KU = NUC / 4;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    constexpr int mq = nx / 16, mu = nu / 16;
+    constexpr int mt = d * mq + mu;
+    const int ntile = (cnt + 15) / 16;
+    int nsplit = nwaves / mt;
+    if (nsplit > ntile) nsplit = ntile;
+    if (nsplit < 1) nsplit = 1;
+    for (int it = wave; it < mt * nsplit; it += nwaves) {
+        const int m = it % mt, sp = it / mt;
+        const bool isx = m < d * mq;
+        const int c = isx ? m / mq : 0, row0 = isx ? (m - c * mq) * 16 : (m - d * mq) * 16;
+        double af[KQ], bf[KU];
+        if (isx) {
+            mfma_load_frags<KQ>(af, SW + dm.sw_oABK + c * nx * nx + (row0 + j), nx, kq, KQ, 0);
+            mfma_load_frags<KU>(bf, Bm + slot_event(c, d) * nx * nu + (row0 + j), nx, kq, KU, 0);
+        } else {
+            mfma_load_frags<KQ>(af, SW + dm.sw_oK + (row0 + j), nu, kq, KQ, 0);
+#pragma unroll
+            for (int q = 0; q < KU; ++q) bf[q] = 0.;
+        }
+        for (int nt = sp; nt < ntile; nt += nsplit) {
+            const int pos = nt * 16 + j;
+            const bool valid = pos < cnt;
+            const int li = lvl_first + (valid ? pos : 0), posv = valid ? pos : 0;
+            const double *xi = L.XQ + (long)li * nx, *di = L.ED + (long)li * nu;
+            spk_v4d acc = {0., 0., 0., 0.};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const double bv = valid ? xi[4 * q + kq] : 0.;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bv, acc, 0, 0, 0);
+            }
+            if (isx) {
+#pragma unroll
+                for (int q = 0; q < KU; ++q) {
+                    const double bv = valid ? di[4 * q + kq] : 0.;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[q], bv, acc, 0, 0, 0);
+                }
+                if (valid) {
+                    double *dst = kids_gleaf ? L.XL + (long)(posv * d + c) * nx : L.XQ + (long)(li * d + 1 + c) * nx;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) dst[row0 + kq + 4 * reg] = acc[reg];
+                }
+            } else if (valid) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) { const int r = row0 + kq + 4 * reg; L.UL[(long)li * nu + r] = acc[reg] + di[r]; }
+            }
+        }
+    }
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // Register-resident lane-team sweep (P::REGROWS).  Thread w <-> (node li = w / T, row r = w % T) for the WHOLE sweep;
 // it loads its rows of W, V, ABK, B, K of its node's stage once, up front, so that a tree level costs one LDS read of
 // the children's / parent's vector, ~2 d nx FMAs, one LDS write and the barrier -- no memory access on the dependent

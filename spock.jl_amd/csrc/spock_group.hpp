@@ -139,6 +139,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
     // ---- team sweeps: carve the LDS vectors (spock_device.hpp: TeamLds)
     const int team = sweeping ? a.team : 0;
+#ifndef SPOCK_HOST_EMU
+    // sweep levels as matrix products on the matrix cores (spock_device.hpp: bwd_level_mfma) when the blocks fill 16 x 16 tiles
+    const bool use_mfma = team > 0 && !(P::REGROWS && a.team_reg) && mfma_sweep_applies(p.nx(), p.nu(), p.d()) && !a.no_mfma;
+#endif
     const int nl_grp = group_threads_dev(p.d(), stages);          // non-leaf nodes of this group
     int ngl_grp = 1;                                               // leaves of this group
     for (int k = 0; k < stages - 1; ++k) ngl_grp *= p.d();
@@ -281,6 +285,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 } else {
                     const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
+#ifndef SPOCK_HOST_EMU
+                    if (use_mfma) x.each([&](int tid, TState<P> &) { bwd_level_mfma<64, 16, 2>(p, dm, SW, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                    else
+#endif
                     x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 }
                 x.barrier();
@@ -362,6 +370,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, lmB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 } else {
                     const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
+#ifndef SPOCK_HOST_EMU
+                    if (use_mfma) x.each([&](int tid, TState<P> &) { fwd_level_mfma<64, 16, 2>(p, dm, SW, gB, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                    else
+#endif
                     x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, gB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 }
                 x.barrier();

@@ -220,7 +220,7 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     while (T < nx || T < nu) T *= 2;
     const long mats_bytes = ((long)(max_stages - 1) * dm.sw_stride + (long)d * nx * nu) * 8;
     // 160 KiB of LDS per CU on MI355X; the launcher raises the dynamic-LDS limit of the kernel when more than 64 KiB is used
-    const long budget = 144 * 1024, tail = (4 + 128 + 64) * 8;   // reduction scratch + flag, 64 diagnostic clock stamps, SP sum reduction
+    const long budget = 156 * 1024, tail = (4 + 128 + 64) * 8;   // (160 KiB per CU; a few KiB stay free for the kernel's own needs)   // reduction scratch + flag, 64 diagnostic clock stamps, SP sum reduction
     // Lane teams pay off when a node's mat-vecs are big (measured on MI355X: nx = nu = 20, N = 10: 3058 -> 561 us per
     // iteration).  For the small compile-time shapes (nx <= 8) one thread per node with the vectors in registers and
     // the matrices in SGPRs is as fast per level and keeps workgroups at one wave, which the batched regime needs
@@ -251,7 +251,10 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
         // behind the sweep vectors; 256 threads when that scratch does not fit
         // (1024 threads = one round for 31-node subtrees at T = 32: a further 2-4 %; the crown kernel has no node-local
         // phases and its level barriers are cheaper with 512)
-        for (int thr = (mode == MODE_CROWN ? 512 : 1024); thr >= 256 && !g.team_local; thr /= 2) {
+        // (crown: 512 threads for the scalar level kernels, whose barriers are cheaper then; 1024 = 16 waves for the MFMA levels,
+        //  which have 5 / 9 row tiles of work items per level, times the shares of the node tiles)
+        const bool mfma_lv = (nx == 64 && nu == 16 && d == 2) && !std::getenv("SPOCK_AMD_NO_MFMA");
+        for (int thr = ((mode == MODE_CROWN && !mfma_lv) ? 512 : 1024); thr >= 256 && !g.team_local; thr /= 2) {
             if (const char *e = std::getenv("SPOCK_AMD_TL_THREADS")) thr = std::atoi(e);
             const int nteams = thr / g.team;
             const long scr = (long)nteams * ((dm.ny + 2 * d) + nu + (2 + 2 * d) * g.team);

@@ -108,6 +108,8 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     // instances); with a handful of workgroups the copy is pure latency in front of the sweep (+3 us per kernel)
     bool stage = g.lds_mats && ((long)a.batch * g.grid_x >= 1024 || g.team);
     if (const char *e = std::getenv("SPOCK_AMD_LDS_MATS")) stage = g.lds_mats && e[0] == '1';
+    static const bool no_mfma = std::getenv("SPOCK_AMD_NO_MFMA") != nullptr;
+    a.no_mfma = no_mfma ? 1 : 0;
     a.lds_mats = stage ? 1 : 0; a.team = g.team; a.team_reg = g.team_reg; a.ex_doubles = g.ex_doubles;
     a.xl_global = (g.team && g.xl_global && a.xlbuf) ? 1 : 0; a.xl_stride = g.xl_stride;
     if (g.team && g.xl_global && !a.xlbuf) return (int)hipErrorInvalidValue;

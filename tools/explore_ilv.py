@@ -14,6 +14,7 @@ x0 = 0.1 * (1.0 + 0.001 * np.arange(B))[:, None] * np.ones((B, 5))
 o = O.Oracle(flat, O.CP); o.solve(x0[B // 3], tol=0.0, max_iter=M)
 for lay in layouts:
     kw = {}
+    if os.environ.get("LIB"): kw["lib_path"] = os.environ["LIB"]
     if os.environ.get("SPLIT"): kw["split_stage"] = int(os.environ["SPLIT"])
     m = S.build_model(*specs, batch=B, layout=lay, max_iter=M, graph_iters=M, **kw)
     S.solve_model(m, x0, tol=0.0); m.reset()
