@@ -61,7 +61,9 @@ typedef struct spock_handle_s *spock_handle_t;
  *   dynamics    -> A, B indexed by event           (src/dynamics.jl:1-4)
  *   cost        -> Q, R per non-root node, QN per leaf; a count of 1 means "one matrix shared by all"
  *                  (src/cost.jl:3-7)
- *   rms         -> E, F, b and the cone list of K; uniform over the non-leaf nodes (src/risk_measures.jl:79-84)
+ *   rms         -> E, F, b and the cone list of K (src/risk_measures.jl:79-84): one risk measure shared by all non-leaf nodes
+ *                  (n_rms = 1: get_uniform_rms_v2, :93-102) or one per non-leaf node (n_rms = n_nonleaf:
+ *                  get_nonuniform_rms_avar_v2, :127-136); length(b) and K are common to all (implicit_l.jl:14,19)
  *   constraints -> UniformRectangle bounds          (src/constraints.jl:11-22)
  */
 typedef struct {
@@ -76,13 +78,14 @@ typedef struct {
     const double *Q;      /* [nQ][nx*nx] */
     const double *R;      /* [nR][nu*nu] */
     const double *QN;     /* [nQN][nx*nx] */
-    const double *E;      /* [ny*d]  (ny x d) */
-    const double *F;      /* [ny*d]  (ny x d) */
-    const double *b;      /* [ny] */
+    const double *E;      /* [n_rms][ny*d]  (ny x d) */
+    const double *F;      /* [n_rms][ny*d]  (ny x d) */
+    const double *b;      /* [n_rms][ny] */
     int32_t n_cones;      /* subcones of K, dimensions add up to ny */
     const int32_t *cone_kind;
     const int32_t *cone_dim;
     double x_min, x_max, u_min, u_max;
+    int32_t n_rms;        /* 0 / 1: E, F, b hold one risk measure; n_nonleaf: one (ny x d), (ny x d), (ny) block per non-leaf node */
 } spock_problem_t;
 
 /* SolverOptions (src/model.jl:71-74) plus what a GPU needs to know.  Zero / NaN selects the default. */

@@ -25,7 +25,7 @@ class _Problem(C.Structure):
                 ("Q", C.c_void_p), ("R", C.c_void_p), ("QN", C.c_void_p),
                 ("E", C.c_void_p), ("F", C.c_void_p), ("b", C.c_void_p),
                 ("n_cones", C.c_int), ("cone_kind", C.c_void_p), ("cone_dim", C.c_void_p),
-                ("x_min", C.c_double), ("x_max", C.c_double), ("u_min", C.c_double), ("u_max", C.c_double)]
+                ("x_min", C.c_double), ("x_max", C.c_double), ("u_min", C.c_double), ("u_max", C.c_double), ("n_rms", C.c_int)]
 
 
 class _Result(C.Structure):
@@ -91,7 +91,7 @@ class Oracle:
         pr = _Problem(flat.N, flat.d, flat.nx, flat.nu, flat.ny, _p(flat.A), _p(flat.B), flat.nQ, flat.nR, flat.nQN,
                       _p(flat.Q), _p(flat.R), _p(flat.QN), _p(flat.E), _p(flat.F), _p(flat.b),
                       len(flat.cone_kind), _p(flat.cone_kind), _p(flat.cone_dim),
-                      flat.x_min, flat.x_max, flat.u_min, flat.u_max)
+                      flat.x_min, flat.x_max, flat.u_min, flat.u_max, getattr(flat, "n_rms", 1))
         self.h = lib().orc_create(C.byref(pr), algorithm)
         if not self.h:
             raise ValueError("oracle: invalid problem")

@@ -49,10 +49,12 @@ typedef struct {
     const double *A, *B;       /* d matrices each, nx*nx and nx*nu, column-major */
     int nQ, nR, nQN;           /* 1 = one shared matrix, else n-1 / n-1 / nl */
     const double *Q, *R, *QN;
-    const double *E, *F, *b;   /* ny x d, ny x d, ny */
+    const double *E, *F, *b;   /* n_rms blocks of ny x d, ny x d, ny */
     int n_cones;
     const int *cone_kind, *cone_dim;
     double x_min, x_max, u_min, u_max;
+    int n_rms;                 /* 1: one risk measure shared by all non-leaf nodes (get_uniform_rms_v2, risk_measures.jl:93-102), else one
+                                  per non-leaf node with a common length(b) and cone (get_nonuniform_rms_avar_v2, :127-136) */
 } orc_problem;
 
 typedef struct {
@@ -68,7 +70,7 @@ typedef struct {
     int zx, zu, zs, zt, zy;
     int o2, o3, o4, o5, o6, o7, o11, o12, o13, o14; /* v offsets; v1 at 0 */
     double *A, *B;
-    int nQ, nR, nQN;
+    int nQ, nR, nQN, n_rms;
     double *sqrtQ, *sqrtR, *sqrtQN;
     double *b;
     int n_cones, *ck, *cd;
@@ -296,7 +298,7 @@ static void ricatti_offline(orc *o) { /* implicit_l.jl:46-97 */
 /* Orthogonal projector onto ker [E' -I -I ; F' 0 0]  (cpock.jl:71-81,125-128).
    The reference forms U*pinv(U) with U from an SVD of a null-space basis, i.e. the unique orthogonal
    projector; here: I - W W' with W an orthonormal basis of the row space (MGS with re-orthogonalisation). */
-static void kernel_projector(orc *o, const double *E, const double *F) {
+static void kernel_projector(orc *o, const double *E, const double *F, double *ls_out) {
     int d = o->d, ny = o->ny, m = ny + 2 * d;
     double *W = dalloc((size_t)2 * d * m), *r = dalloc(m);
     int rank = 0;
@@ -325,12 +327,11 @@ static void kernel_projector(orc *o, const double *E, const double *F) {
         for (int i = 0; i < m; i++) W[i + rank * m] = r[i] / n1;
         rank++;
     }
-    o->ls = dalloc((size_t)m * m);
     for (int c = 0; c < m; c++)
         for (int rr = 0; rr < m; rr++) {
             double s = 0.;
             for (int q = 0; q < rank; q++) s += W[rr + q * m] * W[c + q * m];
-            o->ls[rr + c * m] = (rr == c ? 1. : 0.) - s;
+            ls_out[rr + c * m] = (rr == c ? 1. : 0.) - s;
         }
     free(W); free(r);
 }
@@ -364,7 +365,8 @@ orc *orc_create(const orc_problem *p, int alg) {
     for (int k = 0; k < o->nQ; k++) sym_sqrt(nx, p->Q + (size_t)k * nx * nx, o->sqrtQ + (size_t)k * nx * nx);
     for (int k = 0; k < o->nR; k++) sym_sqrt(nu, p->R + (size_t)k * nu * nu, o->sqrtR + (size_t)k * nu * nu);
     for (int k = 0; k < o->nQN; k++) sym_sqrt(nx, p->QN + (size_t)k * nx * nx, o->sqrtQN + (size_t)k * nx * nx);
-    o->b = dalloc(ny); memcpy(o->b, p->b, sizeof(double) * ny);
+    o->n_rms = p->n_rms > 1 ? p->n_rms : 1;
+    o->b = dalloc((size_t)o->n_rms * ny); memcpy(o->b, p->b, sizeof(double) * ny * o->n_rms);
     o->n_cones = p->n_cones;
     o->ck = (int *)malloc(sizeof(int) * (p->n_cones ? p->n_cones : 1));
     o->cd = (int *)malloc(sizeof(int) * (p->n_cones ? p->n_cones : 1));
@@ -377,7 +379,9 @@ orc *orc_create(const orc_problem *p, int alg) {
       for (int t = 0; t < N; t++) { for (int k = 0; k < cnt; k++) o->stage[first + k] = t; first += cnt; cnt *= d; } }
 
     ricatti_offline(o);
-    kernel_projector(o, p->E, p->F);
+    o->ls = dalloc((size_t)o->n_rms * (ny + 2 * d) * (ny + 2 * d));
+    for (int k = 0; k < o->n_rms; k++)   /* Ms[i] of cpock.jl:71-81 is built from rms[i].E, rms[i].F */
+        kernel_projector(o, p->E + (size_t)k * ny * d, p->F + (size_t)k * ny * d, o->ls + (size_t)k * (ny + 2 * d) * (ny + 2 * d));
 
     int nz = o->nz, nv = o->nv, m = ny + 2 * d;
     o->x0 = dalloc(nx);
@@ -453,7 +457,7 @@ void orc_L(orc *o, const double *z, double *v) { /* implicit_l.jl:177-318 */
     for (int k = 0; k < nn * ny; k++) v[k] = z[o->zy + k];                                   /* v1 :208-210 */
     for (int i = 0; i < nn; i++) {                                                           /* v2 :214-222 */
         double dot_p = 0.;
-        for (int k = 0; k < ny; k++) dot_p += o->b[k] * z[o->zy + i * ny + k];
+        for (int k = 0; k < ny; k++) dot_p += mat_sel(o->b, o->n_rms, i, ny)[k] * z[o->zy + i * ny + k];   /* rms[i].b (:219) */
         v[o->o2 + i] = z[o->zs + i] - dot_p;
     }
     for (int i = 0; i < nn; i++)                                                             /* v3 :226-235 */
@@ -508,7 +512,7 @@ void orc_Lt(orc *o, double *z, const double *v) { /* implicit_l.jl:320-449 */
             for (int k = 0; k < nu; k++) z[o->zu + i * nu + k] += o->mul_u[k];
         }
     for (int i = 0; i < nn; i++)                                                             /* y :423-429 */
-        for (int k = 0; k < ny; k++) z[o->zy + i * ny + k] = v[i * ny + k] - o->b[k] * v[o->o2 + i];
+        for (int k = 0; k < ny; k++) z[o->zy + i * ny + k] = v[i * ny + k] - mat_sel(o->b, o->n_rms, i, ny)[k] * v[o->o2 + i];   /* rms[i].b (:427) */
     for (int jn = 0; jn < o->n - 1; jn++) z[o->zt + jn] = 0.5 * v[o->o5 + jn] + 0.5 * v[o->o6 + jn]; /* tau :432-437 */
     for (int i = 0; i < nn; i++) z[o->zs + i] = v[o->o2 + i];                                /* s non-leaf :440-442 */
     for (int i = 0; i < nl; i++) z[o->zs + nn + i] = 0.5 * v[o->o12 + i] + 0.5 * v[o->o13 + i]; /* s leaf :445-448 */
@@ -600,7 +604,7 @@ static void projection_S2(orc *o, double *z2) { /* implicit_l.jl:688-727; z2 = (
         memcpy(o->ls_b, z2 + y_off + i * ny, sizeof(double) * ny);
         memcpy(o->ls_b + ny, z2 + c1, sizeof(double) * d);
         memcpy(o->ls_b + ny + d, z2 + tau_off + c1, sizeof(double) * d);
-        gemv_n(m, m, o->ls, o->ls_b, o->ls_b2);
+        gemv_n(m, m, mat_sel(o->ls, o->n_rms, i, m * m), o->ls_b, o->ls_b2);   /* ls_matrix[i] (:717) */
         memcpy(z2 + y_off + i * ny, o->ls_b2, sizeof(double) * ny);
         memcpy(z2 + c1, o->ls_b2 + ny, sizeof(double) * d);
         memcpy(z2 + tau_off + c1, o->ls_b2 + ny + d, sizeof(double) * d);

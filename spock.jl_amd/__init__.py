@@ -5,7 +5,7 @@ the C ABI in include/spock_amd.h (libspock_amd.so: hand-written HIP kernels for 
 """
 from .problem import (CONE_NONNEG, CONE_NONPOS, CONE_REALS, CONE_SOC, CONE_ZEROS, ConvexCone, Cost, Dynamics,
                       FlatProblem, RiskMeasure, ScenarioTree, UniformRectangle, flatten_problem,
-                      generate_scenario_tree_uniform_branching_factor_v2, get_uniform_rms_avar_v2,
+                      generate_scenario_tree_uniform_branching_factor_v2, get_nonuniform_rms_avar_v2, get_uniform_rms_avar_v2,
                       get_uniform_rms_tv_v2, get_uniform_rms_v2)
 from .model import (CP, LOG, SILENT, SP, AlgorithmOptions, Model, QNewtonOptions, SolverOptions, VERBOSE_LEVEL,
                     build_model, mpc_simulation, solve_model, solve_model_bang)

@@ -26,7 +26,7 @@ class Problem(C.Structure):
                 ("Q", C.c_void_p), ("R", C.c_void_p), ("QN", C.c_void_p),
                 ("E", C.c_void_p), ("F", C.c_void_p), ("b", C.c_void_p),
                 ("n_cones", C.c_int32), ("cone_kind", C.c_void_p), ("cone_dim", C.c_void_p),
-                ("x_min", C.c_double), ("x_max", C.c_double), ("u_min", C.c_double), ("u_max", C.c_double)]
+                ("x_min", C.c_double), ("x_max", C.c_double), ("u_min", C.c_double), ("u_max", C.c_double), ("n_rms", C.c_int32)]
 
 
 class Options(C.Structure):

@@ -482,9 +482,14 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     hp.Q.assign(p->Q, p->Q + (size_t)hp.nQ * nx * nx);
     hp.R.assign(p->R, p->R + (size_t)hp.nR * nu * nu);
     hp.QN.assign(p->QN, p->QN + (size_t)hp.nQN * nx * nx);
-    hp.E.assign(p->E, p->E + (size_t)ny * d);
-    hp.F.assign(p->F, p->F + (size_t)ny * d);
-    hp.b.assign(p->b, p->b + ny);
+    {
+        const long nn_ = (nl - 1) / (d - 1);
+        hp.n_rms = p->n_rms > 1 ? p->n_rms : 1;
+        if (hp.n_rms > 1 && hp.n_rms != nn_) { delete h; return fail(SPOCK_ERR_BAD_ARG, "n_rms must be 0 / 1 or the number of non-leaf nodes"); }
+    }
+    hp.E.assign(p->E, p->E + (size_t)hp.n_rms * ny * d);
+    hp.F.assign(p->F, p->F + (size_t)hp.n_rms * ny * d);
+    hp.b.assign(p->b, p->b + (size_t)hp.n_rms * ny);
     hp.cone_kind.assign(p->cone_kind, p->cone_kind + p->n_cones);
     hp.cone_dim.assign(p->cone_dim, p->cone_dim + p->n_cones);
     hp.x_min = p->x_min; hp.x_max = p->x_max; hp.u_min = p->u_min; hp.u_max = p->u_max;
@@ -514,7 +519,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     int layout = o ? o->batch_layout : 0;
     if (const char *e = std::getenv("SPOCK_AMD_ILV")) layout = (e[0] == '1') ? 2 : 1;
     if (layout < 0 || layout > 2) { delete h; return fail(SPOCK_ERR_BAD_ARG, "batch_layout must be 0 (choose), 1 (instance-major) or 2 (element-major)"); }
-    const bool ilv_possible = alg == SPOCK_ALG_CP && N >= 3 && have_static_variant(nx, nu, d, ny) && hp.nQ == 1 && hp.nR == 1 && hp.nQN == 1;
+    const bool ilv_possible = alg == SPOCK_ALG_CP && N >= 3 && have_static_variant(nx, nu, d, ny) && hp.nQ == 1 && hp.nR == 1 && hp.nQN == 1 && hp.n_rms == 1;
     if (layout == 2 && !ilv_possible) { delete h; return fail(SPOCK_ERR_UNSUPPORTED, "the element-major batch layout exists for CP, the compile-time shapes and shared cost matrices"); }
     bool want_ilv = ilv_possible && (layout == 2 || (layout == 0 && h->batch >= 64));
 

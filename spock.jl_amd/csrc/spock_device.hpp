@@ -274,6 +274,9 @@ SPK_DEV void init_geometry(const P &p, const Dims &dm, int tau, int root_stage, 
 // ------------------------------------------------------------------------------------------------
 // phase A, node-local:  zbar0 = (-gamma) L'v + z on the entries owned by node i, then S2, then the
 // node-local terms of the S1 recursion: c_i = U_t ubar_i - xbar_i and e_i = Rt^-1 ubar_i (spock_host.cpp).
+template <class P, class ZO>
+SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s, const double *xbar, const double *ubar, const double *vec);
+
 template <class P, class ZI, class VI, class ZO, class V2>
 SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, TState<P> &s, double gamma, unsigned flags, V2 v2x) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
@@ -306,7 +309,7 @@ SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, 
     // [y_i ; s_children ; tau_children]  (implicit_l.jl:423-448)
     double vec[P::MAXM];
     const double v2i = v[dm.o2 + i];
-    const MatPtr bb = M + dm.mb;
+    const MatPtr bb = M + dm.mb + (dm.nRm > 1 ? i * ny : 0);          // rms[i].b (implicit_l.jl:427)
     SPK_UNROLL for (int k = 0; k < ny; ++k) vec[k] = mg * (v[i * ny + k] - bb[k] * v2i) + z[dm.zy + i * ny + k];
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = s.c0 + c;
@@ -343,9 +346,18 @@ SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, 
     // s_1: (z - gamma L'v)[s_1] - gamma  (prox_f!, implicit_l.jl:741)
     if (i == 0) zo[dm.zs] = (mg * v[dm.o2] + z[dm.zs]) - gamma;
     spk_block_fence<ZI>();
+    a_finish(p, dm, M, zo, s, xbar, ubar, vec);
+}
+
+// second half of phase A: S2 on [y_i; s_ch; tau_ch] = vec (its part of the next zbar goes to zo), then the node-local terms of
+// the S1 recursion c_i -> s.xb, e_i -> s.ub from xbar, ubar (the leaves' xbar stays in s.xl)
+template <class P, class ZO>
+SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s, const double *xbar, const double *ubar, const double *vec) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
+    const int i = s.node;
     // S2: projector onto ker [E' -I -I ; F' 0 0] applied to [y_i; s_ch; tau_ch]  (implicit_l.jl:708-726)
     const int m = ny + 2 * d;
-    const MatPtr LS = M + dm.mLs;
+    const MatPtr LS = M + dm.mLs + (dm.nRm > 1 ? i * m * m : 0);       // ls_matrix[i] (implicit_l.jl:717)
     SPK_UNROLL for (int r = 0; r < m; ++r) {
         double t = 0.;
         SPK_UNROLL for (int k = 0; k < m; ++k) t += LS[r + k * m] * vec[k];
@@ -353,7 +365,7 @@ SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, 
         else if (r < ny + d) zo[dm.zs + s.c0 + (r - ny)] = t;
         else zo[dm.zt + s.c0 + (r - ny - d) - 1] = t;
     }
-    spk_block_fence<ZI>();
+    spk_block_fence<ZO>();
     // node-local terms of the S1 recursion
     const MatPtr Ut = M + dm.mU + s.stage * nx * nu;
     const MatPtr Ri = M + dm.mRinv + s.stage * nu * nu;
@@ -734,7 +746,7 @@ struct ProxScal {
 template <class P, class ZI, class VI, class ZB>
 SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, int j, const ProxScal &ps) {
     const int ny = p.ny();
-    const MatPtr bb = M + dm.mb;
+    const MatPtr bb = M + dm.mb + (dm.nRm > 1 ? j * ny : 0);
     double bw = 0.;
     SPK_UNROLL for (int k = 0; k < ny; ++k) {
         const double zbk = zb[dm.zy + j * ny + k], zk = z[dm.zy + j * ny + k];
@@ -749,6 +761,14 @@ SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB
     return ps.sigma * (t2 - p2);
 }
 
+// Phase A of the NEXT iteration gathered while phase B of this one has its results in registers (element-major kernels, nodes
+// whose children are leaves): z <- zbar, v <- vbar at lambda = 1 (cp.jl:34-52), so (-gamma) L'vbar + zbar on the node's own
+// entries needs nothing from memory.  ax / au accumulate (L'vbar) on x_i / u_i, vec = [y_i; s_ch; tau_ch], xl the leaves' xbar.
+template <class P>
+struct ANext {
+    double ax[P::MAXNX], au[P::MAXNU], vec[P::MAXM], xl[P::MAXD][P::MAXNX];
+};
+
 // SPM (SP driver, spock_sp.hpp): the inner products of run_sp! that involve the residual r = (z, v) - T(z, v) of THIS
 // evaluation, accumulated where its pieces are at hand instead of in a separate pass that applies L and L' again.
 // With dz = zbar - z, dv = vbar - v and the termination residuals xi_1 = L'dv - dz/gamma, xi_2 = L dz - dv/sigma:
@@ -761,9 +781,10 @@ SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB
 template <class P, int SPM, int PART, class ZI, class VI, class ZB, class VO>
 SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, VO vo, TState<P> &s,
                        const ProxScal &ps, unsigned flags, double *mx, double *sp = nullptr, const double *dirz = nullptr,
-                       const double *dirv = nullptr) {
+                       const double *dirv = nullptr, ANext<P> *an = nullptr) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu;
+    const double mgn = -ps.gamma;   // (an: next phase A)
     const double sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0, wx = ps.want_xi;
     double m1 = mx[0], m2 = mx[1], m3 = mx[2];
@@ -808,7 +829,7 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
 
     // ---- v1, v2 : risk-measure block of node i -------------------------------------------------
     if (MAIN) {
-        const MatPtr bb = M + dm.mb;
+        const MatPtr bb = M + dm.mb + (dm.nRm > 1 ? i * ny : 0);      // rms[i].b (implicit_l.jl:219)
         double wy[P::MAXNY], dzy[P::MAXNY], t1[P::MAXNY], pr[P::MAXNY];
         double bw = 0., bdz = 0.;
         SPK_UNROLL for (int k = 0; k < ny; ++k) {
@@ -876,6 +897,7 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
         spk_resmax<ZI>(m2, x2, poison);
         acc_v(dm.o2 + i, dv2, x2);
         vo[dm.o2 + i] = nv2;
+        if (an) { SPK_UNROLL for (int k = 0; k < ny; ++k) an->vec[k] = mgn * (pr[k] - bb[k] * nv2) + (wy[k] - dzy[k]); }   // zbar.y = w - dz
         SPK_UNROLL for (int k = 0; k < ny; ++k) {
             const double dv1 = pr[k] - v[i * ny + k];
             vo[i * ny + k] = pr[k];
@@ -907,6 +929,7 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
                 nvv = sg * (t - pj);
             }
             vo[dm.o7 + i * nxu + k] = nvv;
+            if (an) { if (isx) an->ax[k] = nvv; else an->au[k - nx] = nvv; }
             const double dv = nvv - vin;
             const double x2 = dzv + nis * dv;
             spk_resmax<ZI>(m2, x2, poison);
@@ -952,6 +975,11 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
         SPK_UNROLL for (int r = 0; r < nx; ++r) { vo[dm.o3 + jn * nx + r] = pj[1 + r]; tt[1 + r] = pj[1 + r] - v[dm.o3 + jn * nx + r]; }
         SPK_UNROLL for (int r = 0; r < nu; ++r) { vo[dm.o4 + jn * nu + r] = pj[1 + nx + r]; tt[1 + nx + r] = pj[1 + nx + r] - v[dm.o4 + jn * nu + r]; }
         vo[dm.o5 + jn] = pj[1 + nxu];
+        if (an) {   // L'vbar on x_i, u_i and on tau_j (implicit_l.jl:365-373, :412-420, :432-437)
+            sym_mv<P, true>(nx, SQ, pj + 1, an->ax);
+            sym_mv<P, true>(nu, SR, pj + 1 + nx, an->au);
+            an->vec[ny + d + c] = mgn * (0.5 * pj[1 + nxu] + 0.5 * pj[0]) + zbt;
+        }
         tt[1 + nxu] = pj[1 + nxu] - v[dm.o5 + jn];
         SPK_UNROLL for (int k = 0; k < len; ++k) { lz[k] = lz[k] + nis * tt[k]; spk_resmax<ZI>(m2, lz[k], poison); }
         if (SPM >= 1) {
@@ -1007,6 +1035,11 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
             t3[0] = p3[0] - v[dm.o13 + li];
             SPK_UNROLL for (int r = 0; r < nx; ++r) { vo[dm.o11 + li * nx + r] = p3[1 + r]; t3[1 + r] = p3[1 + r] - v[dm.o11 + li * nx + r]; }
             vo[dm.o12 + li] = p3[1 + nx];
+            double q11[P::MAXNX];
+            if (an) {   // s_leaf and x_leaf entries of (-gamma) L'vbar + zbar (implicit_l.jl:376-396, :445-448)
+                an->vec[ny + c] = mgn * (0.5 * p3[1 + nx] + 0.5 * p3[0]) + zbs;
+                sym_mv<P, false>(nx, SN, p3 + 1, q11);
+            }
             t3[1 + nx] = p3[1 + nx] - v[dm.o12 + li];
             SPK_UNROLL for (int k = 0; k < l2; ++k) { l3[k] = l3[k] + nis * t3[k]; spk_resmax<ZI>(m2, l3[k], poison); }
             if (SPM >= 1) {
@@ -1024,6 +1057,7 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
                 if (noprox) nvv = t;
                 else { t = t * isg; nvv = sg * (t - spk_clamp(t, dm.x_min, dm.x_max)); }
                 vo[dm.o14 + li * nx + r] = nvv;
+                if (an) an->xl[c][r] = mgn * (nvv + q11[r]) + s.xl[c][r];
                 const double dv = nvv - vin;
                 const double x2 = dl[r] + nis * dv;
                 spk_resmax<ZI>(m2, x2, poison);

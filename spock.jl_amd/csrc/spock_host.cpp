@@ -220,7 +220,9 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     while (T < nx || T < nu) T *= 2;
     const long mats_bytes = ((long)(max_stages - 1) * dm.sw_stride + (long)d * nx * nu) * 8;
     // 160 KiB of LDS per CU on MI355X; the launcher raises the dynamic-LDS limit of the kernel when more than 64 KiB is used
-    const long budget = 156 * 1024, tail = (4 + 128 + 64) * 8;   // (160 KiB per CU; a few KiB stay free for the kernel's own needs)   // reduction scratch + flag, 64 diagnostic clock stamps, SP sum reduction
+    // (config 5's shape: 12 KiB more let the subtree kernels run 1024 threads = 16 lane teams next to the sweep vectors; for the
+    //  other shapes the measured optimum of the geometry rules below was found with 144 KiB)
+    const long budget = ((nx == 64 && nu == 16 && d == 2) ? 156 : 144) * 1024, tail = (4 + 128 + 64) * 8;   // reduction scratch + flag, 64 diagnostic clock stamps, SP sum reduction
     // Lane teams pay off when a node's mat-vecs are big (measured on MI355X: nx = nu = 20, N = 10: 3058 -> 561 us per
     // iteration).  For the small compile-time shapes (nx <= 8) one thread per node with the vectors in registers and
     // the matrices in SGPRs is as fast per level and keeps workgroups at one wave, which the batched regime needs
@@ -405,26 +407,35 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
         }
     }
 
-    // ---- projector onto ker M, M = [E' -I -I ; F' 0 0]: Pi = I - M' (M M')^+ M (cpock.jl:71-81,125-128)
+    // ---- projector onto ker M, M = [E' -I -I ; F' 0 0]: Pi = I - M' (M M')^+ M (cpock.jl:71-81,125-128), one per risk measure
     const int m = ny + 2 * d;
-    Mat Mk(2 * d, m);
-    for (int k = 0; k < d; ++k) {
-        for (int i = 0; i < ny; ++i) { Mk(k, i) = hp.E[(size_t)i + (size_t)k * ny]; Mk(d + k, i) = hp.F[(size_t)i + (size_t)k * ny]; }
-        Mk(k, ny + k) = -1.; Mk(k, ny + d + k) = -1.;
+    const int nRm = hp.n_rms > 1 ? hp.n_rms : 1;
+    if (nRm > 1 && nRm != dm.nn) return "n_rms must be 1 or the number of non-leaf nodes";
+    dm.nRm = nRm;
+    std::vector<double> ls_all;
+    ls_all.reserve((size_t)nRm * m * m);
+    for (int q = 0; q < nRm; ++q) {
+        const double *Eq = hp.E.data() + (size_t)q * ny * d, *Fq = hp.F.data() + (size_t)q * ny * d;
+        Mat Mk(2 * d, m);
+        for (int k = 0; k < d; ++k) {
+            for (int i = 0; i < ny; ++i) { Mk(k, i) = Eq[(size_t)i + (size_t)k * ny]; Mk(d + k, i) = Fq[(size_t)i + (size_t)k * ny]; }
+            Mk(k, ny + k) = -1.; Mk(k, ny + d + k) = -1.;
+        }
+        Mat G = mul(Mk, T(Mk)), V;
+        std::vector<double> w;
+        sym_eig(G, V, w);
+        double wmax = 0.;
+        for (double x : w) wmax = std::fabs(x) > wmax ? std::fabs(x) : wmax;
+        Mat Gp(2 * d, 2 * d);
+        for (int k = 0; k < 2 * d; ++k) {
+            if (!(w[k] > 1e-12 * wmax)) continue;
+            for (int j = 0; j < 2 * d; ++j) for (int i = 0; i < 2 * d; ++i) Gp(i, j) += V(i, k) * V(j, k) / w[k];
+        }
+        Mat ls = Mat::eye(m), MtGM = mul(mul(T(Mk), Gp), Mk);
+        for (size_t k = 0; k < ls.a.size(); ++k) ls.a[k] -= MtGM.a[k];
+        for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { const double s2 = 0.5 * (ls(i, j) + ls(j, i)); ls(i, j) = s2; ls(j, i) = s2; }
+        ls_all.insert(ls_all.end(), ls.a.begin(), ls.a.end());
     }
-    Mat G = mul(Mk, T(Mk)), V;
-    std::vector<double> w;
-    sym_eig(G, V, w);
-    double wmax = 0.;
-    for (double x : w) wmax = std::fabs(x) > wmax ? std::fabs(x) : wmax;
-    Mat Gp(2 * d, 2 * d);
-    for (int k = 0; k < 2 * d; ++k) {
-        if (!(w[k] > 1e-12 * wmax)) continue;
-        for (int j = 0; j < 2 * d; ++j) for (int i = 0; i < 2 * d; ++i) Gp(i, j) += V(i, k) * V(j, k) / w[k];
-    }
-    Mat ls = Mat::eye(m), MtGM = mul(mul(T(Mk), Gp), Mk);
-    for (size_t k = 0; k < ls.a.size(); ++k) ls.a[k] -= MtGM.a[k];
-    for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { const double s = 0.5 * (ls(i, j) + ls(j, i)); ls(i, j) = s; ls(j, i) = s; }
 
     // ---- pack -----------------------------------------------------------------------------------
     auto &pool = out.mats;
@@ -463,8 +474,8 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
         for (int c = 0; c < d; ++c) push(ABK[(size_t)(t + 1) * d + c].a);
         push(K[t].a);
     }
-    dm.mLs = push(ls.a);
-    out.ls = ls.a;
+    dm.mLs = push(ls_all);
+    out.ls.assign(ls_all.begin(), ls_all.begin() + (size_t)m * m);
     dm.mb = push(hp.b);
     out.sqrtQ.clear(); out.sqrtR.clear(); out.sqrtQN.clear();
     dm.mSqQ = (int)pool.size();
@@ -486,9 +497,12 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
     // beta = |b|^2.  The reference leaves this as a `Todo` and hard-codes 10.0 (cpock.jl:62-63) / 3.28 (models/spock.jl:63-64).
     {
         auto lmax = [&](const Mat &S) { Mat V; std::vector<double> w; sym_eig(S, V, w); double m = 0.; for (double x : w) m = x > m ? x : m; return m; };
-        double best = 0.5, beta = 0.;
-        for (double x : hp.b) beta += x * x;
-        best = std::fmax(best, 1. + 0.5 * (beta + std::sqrt(beta * beta + 4. * beta)));
+        double best = 0.5;
+        for (int q = 0; q < nRm; ++q) {   // the (s_i, y_i) block of node i: beta = |b_i|^2
+            double beta = 0.;
+            for (int k = 0; k < ny; ++k) beta += hp.b[(size_t)q * ny + k] * hp.b[(size_t)q * ny + k];
+            best = std::fmax(best, 1. + 0.5 * (beta + std::sqrt(beta * beta + 4. * beta)));
+        }
         auto Qat = [&](int jn) { return Mat::from(hp.Q.data() + (size_t)(hp.nQ == 1 ? 0 : jn) * nx * nx, nx, nx); };
         auto Rat = [&](int jn) { return Mat::from(hp.R.data() + (size_t)(hp.nR == 1 ? 0 : jn) * nu * nu, nu, nu); };
         const int n_par = (hp.nQ == 1 && hp.nR == 1) ? 1 : nn;     // shared costs: every parent has the same sums

@@ -40,6 +40,12 @@ SPK_DEV int spk_uniform(int x) { return x; }
 SPK_DEV int spk_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }   // wave-uniform by construction: tell the compiler
 #endif
 
+#ifdef SPOCK_ILV_NO_FUSE_A   // experiment builds: phase A of the bottom level re-reads zbar / vbar from memory
+constexpr bool kFuseNextA = false;
+#else
+constexpr bool kFuseNextA = true;
+#endif
+
 template <class P>
 struct IState {
     TState<P> s;
@@ -247,10 +253,24 @@ SPK_DEV void igroup_body(X &x, const KArgs &a, const double *zin_, const double 
                     if (root_stage == 0) fwd_node(p, dm, SW, Bm, tau, lvw(tid), x0, s);
                     else fwd_node(p, dm, SW, Bm, tau, lvw(tid), zo + (dm.zx + (long)root_node * nx), s);
                     fwd_store(p, dm, zo, s);      // x_i, u_i and the x of children that are leaves of the group
-                    b_local_g<P, 0, 0>(p, dm, M, z, v, zo, vo, s, ps, 0u, st.mx);
-                    if (last) {   // the last level's phase A needs nothing from this workgroup's other nodes: right away
-                        a_step(tid, s, zo, vo, zn, z, v, ps, true);
-                        if (bottom_grp) bwd_step(tid, s, tau, l); else store_ce(tid, s);
+                    if (last && bottom_grp && kFuseNextA) {
+                        // children are leaves: the next phase A of this node reads only what this phase B has just produced --
+                        // gathered from registers (ANext), nothing is read back from memory
+                        ANext<P> an;
+                        b_local_g<P, 0, 0>(p, dm, M, z, v, zo, vo, s, ps, 0u, st.mx, nullptr, nullptr, nullptr, &an);
+                        double xbar[P::MAXNX], ubar[P::MAXNU];
+                        for (int k = 0; k < nx; ++k) xbar[k] = -ps.gamma * an.ax[k] + s.xb[k];
+                        for (int k = 0; k < nu; ++k) ubar[k] = -ps.gamma * an.au[k] + s.ub[k];
+                        for (int c = 0; c < d; ++c)
+                            for (int k = 0; k < nx; ++k) s.xl[c][k] = an.xl[c][k];
+                        a_finish(p, dm, M, zn, s, xbar, ubar, an.vec);
+                        bwd_step(tid, s, tau, l);
+                    } else {
+                        b_local_g<P, 0, 0>(p, dm, M, z, v, zo, vo, s, ps, 0u, st.mx);
+                        if (last) {   // the last level's phase A needs nothing from this workgroup's other nodes: right away
+                            a_step(tid, s, zo, vo, zn, z, v, ps, true);
+                            if (bottom_grp) bwd_step(tid, s, tau, l); else store_ce(tid, s);
+                        }
                     }
                 }
             });

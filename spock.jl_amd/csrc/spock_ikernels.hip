@@ -44,6 +44,7 @@ static int launch_ivariant(int mode, const KArgs &a_in, hipStream_t st) {
     const IlvGeo g = ilv_geometry(mode, a_in.dm, a_in.grp_level);
     KArgs a = a_in;
     a.ex_doubles = g.ex_doubles; a.cchunk = g.cchunk; a.n_cchunks = g.n_cchunks;
+
     const dim3 grid(g.grid_x, (unsigned)(a.n_tiles > 0 ? a.n_tiles : a.bp / 64)), block(g.threads);
     const size_t lds = g.lds_bytes;
     if (lds > 64 * 1024) return (int)hipErrorInvalidConfiguration;   // ilv_geometry / choose_split_stage_ilv keep it below

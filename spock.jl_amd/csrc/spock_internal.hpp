@@ -20,6 +20,7 @@ struct Dims {
     int zx, zu, zs, zt, zy;
     int o2, o3, o4, o5, o6, o7, o11, o12, o13, o14;
     int nQ, nR, nQN;
+    int nRm;                   // 1: one risk measure (b, S2 projector) for all non-leaf nodes, else one per non-leaf node
     int n_cones;
     int cone_kind[kMaxCones];  // already the DUAL cone kinds (MOI.dual_set, implicit_l.jl:841)
     int cone_dim[kMaxCones];
@@ -172,7 +173,7 @@ enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, 
 struct HostProblem {
     int N, d, nx, nu, ny;
     std::vector<double> A, B, Q, R, QN, E, F, b;
-    int nQ, nR, nQN;
+    int nQ, nR, nQN, n_rms = 1;
     std::vector<int> cone_kind, cone_dim;
     double x_min, x_max, u_min, u_max;
 };

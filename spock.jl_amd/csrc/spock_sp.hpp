@@ -96,7 +96,7 @@ SPK_DEV void lop_local(const P &p, const Dims &dm, MatPtr M, const double *__res
         const double *bz = b, *bv = b + nz;
         const double *az = A, *av = A ? A + nz : nullptr;
         double sum = 0., m1 = acc[2], m2 = acc[3];
-        const MatPtr bb = M + dm.mb;
+        const MatPtr bb = M + dm.mb + (dm.nRm > 1 ? i * ny : 0);
         // ---- z entries x_i, u_i and v entries v7, v3_c, v4_c
         double bx[P::MAXNX], bu[P::MAXNU], ltx[P::MAXNX], ltu[P::MAXNU];
         SPK_UNROLL for (int k = 0; k < nx; ++k) { bx[k] = bz[dm.zx + i * nx + k]; ltx[k] = bv[dm.o7 + i * nxu + k]; }

@@ -51,7 +51,7 @@ SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
     const int i = t.node;
     const double mg = -gamma;
     const bool raw = (flags & F_RAW_LT) != 0;
-    const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb;
+    const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb + (dm.nRm > 1 ? t.node * p.ny() : 0);
     double *vec = S, *ubs = S + m;
     if (r < nx) {   // x_i[r] <- v7 + sum_j sqrtQ v3_j  (implicit_l.jl:351-373), diagonal sqrtQ
         double acc = v[dm.o7 + i * nxu + r];
@@ -101,7 +101,7 @@ SPK_DEV void ta_p2(const P &p, const Dims &dm, MatPtr M, double *__restrict__ zo
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), m = ny + 2 * d;
     const int i = t.node;
     const double *vec = S, *ubs = S + m;
-    const MatPtr LS = M + dm.mLs;
+    const MatPtr LS = M + dm.mLs + (dm.nRm > 1 ? i * m * m : 0);
     for (int e = r; e < m; e += T) {   // implicit_l.jl:708-726
         double a = 0.;
         for (int k = 0; k < m; ++k) a += LS[e + k * m] * vec[k];
@@ -135,7 +135,7 @@ SPK_DEV void tb_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
     const int i = t.node;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0;
     const double sg = ps.sigma, isg = noprox ? 1. : ps.inv_sigma;
-    const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb;
+    const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb + (dm.nRm > 1 ? t.node * p.ny() : 0);
     double *red = S + m + nu;   // [(2 + 2 d)][T]
     double pb0 = 0., pb1 = 0.;
     if (r < ny) {
@@ -191,7 +191,7 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
     const int i = t.node;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0, wx = ps.want_xi;
     const double sg = ps.sigma, isg = noprox ? 1. : ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
-    const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb;
+    const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb + (dm.nRm > 1 ? t.node * p.ny() : 0);
     const double *red = S + m + nu;
     double m1 = mx[0], m2 = mx[1], m3 = mx[2];
     double sp_z = 0., sp_v = 0., sp_d = 0.;
@@ -376,7 +376,7 @@ SPK_DEV void tlop(const P &p, const Dims &dm, MatPtr M, const double *__restrict
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), nxu = nx + nu, nz = dm.nz;
     const int i = t.node;
     const double nig = -1. / gamma, nis = -1. / sigma;
-    const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb;
+    const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb + (dm.nRm > 1 ? t.node * p.ny() : 0);
     const int nb = B2 ? 2 : 1;
     for (int which = 0; which < nb; ++which) {
         const double *b = which ? B2 : Bv, *bz = b, *bv = b + nz;

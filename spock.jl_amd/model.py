@@ -104,7 +104,7 @@ class Model:
         pr = _lib.Problem(flat.N, flat.d, flat.nx, flat.nu, flat.ny, _ptr(flat.anc), _ptr(flat.w), _ptr(flat.A), _ptr(flat.B),
                           flat.nQ, flat.nR, flat.nQN, _ptr(flat.Q), _ptr(flat.R), _ptr(flat.QN),
                           _ptr(flat.E), _ptr(flat.F), _ptr(flat.b), len(flat.cone_kind), _ptr(flat.cone_kind),
-                          _ptr(flat.cone_dim), flat.x_min, flat.x_max, flat.u_min, flat.u_max)
+                          _ptr(flat.cone_dim), flat.x_min, flat.x_max, flat.u_min, flat.u_max, int(flat.n_rms))
         lay = {None: 0, "auto": 0, "instance": 1, "instance-major": 1, "interleaved": 2, "element-major": 2}.get(layout, layout)
         op = _lib.Options(int(options.algorithm), int(device), self.batch, int(split_stage),
                           float("nan") if L_norm is None else (-1.0 if L_norm == "auto" else float(L_norm)), int(max_iter), int(graph_iters),

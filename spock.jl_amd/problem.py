@@ -117,6 +117,21 @@ def get_uniform_rms_avar_v2(p, alpha, d, N) -> List[RiskMeasure]:
     return get_uniform_rms_v2(E, F, b, ConvexCone([(CONE_NONNEG, 2 * d), (CONE_ZEROS, 1)]), d, N)
 
 
+def get_nonuniform_rms_avar_v2(d, N, rng=None) -> List[RiskMeasure]:
+    """One AV@R per non-leaf node with its own level and reference probabilities (risk_measures.jl:127-136):
+    E_i = [alpha_i I; -I; 1'], b_i = [p_i; 0; 1], alpha_i ~ U(0, 1), p_i a random probability vector.  The reference draws
+    them from Julia's global RNG (not reproducible); here from ``rng`` (numpy Generator, default PCG64(0))."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    K = ConvexCone([(CONE_NONNEG, 2 * d), (CONE_ZEROS, 1)])
+    out = []
+    for _ in range((d ** (N - 1) - 1) // (d - 1)):
+        alpha = rng.random()
+        v = rng.random(d)
+        E = np.vstack([alpha * np.eye(d), -np.eye(d), np.ones((1, d))])
+        out.append(RiskMeasure(E, np.zeros((2 * d + 1, d)), np.concatenate([v / v.sum(), np.zeros(d), [1.0]]), K))
+    return out
+
+
 def get_uniform_rms_tv_v2(p, r, d, N) -> List[RiskMeasure]:
     """Total-variation ball (risk_measures.jl:138-147)."""
     p = np.asarray(p, dtype=np.float64)
@@ -170,6 +185,7 @@ class FlatProblem:
     x_max: float
     u_min: float
     u_max: float
+    n_rms: int = 1          # 1: E, F, b hold one risk measure shared by all non-leaf nodes; else one block per non-leaf node
     n: int = field(init=False)
     nn: int = field(init=False)
     nl: int = field(init=False)
@@ -248,10 +264,16 @@ def flatten_problem(scen_tree: ScenarioTree, cost: Cost, dynamics: Dynamics, rms
     if len(dynamics.A) != d or len(dynamics.B) != d:
         raise ValueError("Dynamics must hold one (A, B) pair per event")
     rm = rms[0]
+    uniform = True
     for other in rms[1:]:
-        if other is not rm and not (np.array_equal(other.E, rm.E) and np.array_equal(other.F, rm.F)
-                                    and np.array_equal(other.b, rm.b) and other.K.subcones == rm.K.subcones):
-            raise NotImplementedError("non-uniform risk measures are out of scope (SURVEY.md section 8 f2)")
+        if other is rm:
+            continue
+        if other.K.subcones != rm.K.subcones or np.asarray(other.b).shape != np.asarray(rm.b).shape:
+            raise NotImplementedError("risk measures must share length(b) and the cone K (implicit_l.jl:14,19)")
+        if not (np.array_equal(other.E, rm.E) and np.array_equal(other.F, rm.F) and np.array_equal(other.b, rm.b)):
+            uniform = False
+    if not uniform and len(rms) != scen_tree.n_non_leaf_nodes:
+        raise ValueError("one risk measure per non-leaf node expected")
     ny = int(np.asarray(rm.b).shape[0])
     nQ, Q = _dedupe(cost.Q, scen_tree.n - 1, nx, nx)
     nR, R = _dedupe(cost.R, scen_tree.n - 1, nu, nu)
@@ -265,10 +287,11 @@ def flatten_problem(scen_tree: ScenarioTree, cost: Cost, dynamics: Dynamics, rms
         anc=np.ascontiguousarray(scen_tree.anc, dtype=np.int32), w=np.ascontiguousarray(scen_tree.w, dtype=np.int32),
         A=_stack_colmajor(dynamics.A, nx, nx), B=_stack_colmajor(dynamics.B, nx, nu),
         nQ=nQ, nR=nR, nQN=nQN, Q=Q, R=R, QN=QN,
-        E=np.ascontiguousarray(np.asarray(rm.E, dtype=np.float64).reshape(-1, order="F")),
-        F=np.ascontiguousarray(np.asarray(rm.F, dtype=np.float64).reshape(-1, order="F")),
-        b=np.ascontiguousarray(rm.b, dtype=np.float64),
+        E=np.ascontiguousarray(np.concatenate([np.asarray(r.E, dtype=np.float64).reshape(-1, order="F") for r in (rms if not uniform else [rm])])),
+        F=np.ascontiguousarray(np.concatenate([np.asarray(r.F, dtype=np.float64).reshape(-1, order="F") for r in (rms if not uniform else [rm])])),
+        b=np.ascontiguousarray(np.concatenate([np.asarray(r.b, dtype=np.float64) for r in (rms if not uniform else [rm])])),
         cone_kind=kinds, cone_dim=dims,
         x_min=float(constraints.x_min), x_max=float(constraints.x_max),
         u_min=float(constraints.u_min), u_max=float(constraints.u_max),
+        n_rms=1 if uniform else len(rms),
     )

@@ -323,10 +323,25 @@ def _variant_specs(S, name):
         return S.get_server_heat_specs(2, 5, 2, nu=2), {}
     if name == "d4_tree":                       # branching factor 4 (run-time dimensions)
         return S.get_server_heat_specs(3, 3, 4, p_ref=[0.1, 0.2, 0.3, 0.4]), {}
+    if name == "nonuniform_avar":               # one AV@R per non-leaf node (risk_measures.jl:127-136): per-node b and S2 projector
+        tree, cost, dyn, _, con = S.get_server_heat_specs(6, 5, 2)
+        return (tree, cost, dyn, S.get_nonuniform_rms_avar_v2(2, 6, np.random.default_rng(7)), con), {"split_stage": 3}
+    if name == "nonuniform_avar_large_nx":      # the same on the lane-team node-local phases
+        tree, cost, dyn, _, con = S.get_random_linear_specs(5, 12, 4)
+        return (tree, cost, dyn, S.get_nonuniform_rms_avar_v2(2, 5, np.random.default_rng(8)), con), {"split_stage": 2}
+    if name == "tv_risk":                       # total-variation risk measure (risk_measures.jl:138-147): ny = 3 d, F != 0
+        tree, cost, dyn, _, con = S.get_server_heat_specs(5, 3, 2)
+        return (tree, cost, dyn, S.get_uniform_rms_tv_v2([0.4, 0.6], 0.2, 2, 5), con), {"split_stage": 2}
+    if name == "nonpos_cone":                   # a Nonpositives sub-cone in K (risk_measures.jl:29-34): AV@R with its second block negated
+        tree, cost, dyn, _, con = S.get_server_heat_specs(5, 5, 2)
+        E = np.vstack([0.95 * np.eye(2), np.eye(2), np.ones((1, 2))]); F = np.zeros((5, 2)); b = np.array([0.3, 0.7, 0, 0, 1.0])
+        rms = S.get_uniform_rms_v2(E, F, b, S.ConvexCone([(S.CONE_NONNEG, 2), (S.CONE_NONPOS, 2), (S.CONE_ZEROS, 1)]), 2, 5)
+        return (tree, cost, dyn, rms, con), {"split_stage": 2}
     raise KeyError(name)
 
 
-VARIANTS = ["per_node_dense_costs", "shared_dense_costs", "per_node_costs_large_nx", "soc_risk_cone", "two_stage_tree", "d4_tree"]
+VARIANTS = ["per_node_dense_costs", "shared_dense_costs", "per_node_costs_large_nx", "soc_risk_cone", "two_stage_tree", "d4_tree",
+            "nonuniform_avar", "nonuniform_avar_large_nx", "tv_risk", "nonpos_cone"]
 
 
 @pytest.mark.parametrize("name", VARIANTS)
@@ -348,6 +363,14 @@ def test_emulated_variants(S, O, emu, name):
     assert (r["iterations"], r["status"]) == (ro["iterations"], ro["status"])
     assert relerr(m.solver_state.z, o.z) <= 1e-8
     m.close()
+    if name.startswith("nonuniform"):     # the SP driver's inner products use rms[i].b as well (spock_dot, implicit_l.jl:485-516)
+        ms = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, L_norm="auto", max_iter=25, **kw)
+        os_ = O.Oracle(flat, O.SP); os_.L_norm = ms.solver_state.L_norm
+        S.solve_model(ms, x0, tol=1e-12, verbose=S.LOG)
+        ro = os_.solve(x0, tol=1e-12, verbose=O.LOG, max_iter=25, history=30)
+        h = ms.history()
+        assert np.max(np.abs(h["xi"] - ro["hist_xi"]) / ro["hist_xi"]) <= 1e-6 and np.array_equal(h["backtrack"], ro["hist_backtrack"])
+        ms.close()
 
 
 @pytest.mark.parametrize("env,ok", [({}, True), ({"SPOCK_EMU_REVERSE_BLOCKS": "1"}, True), ({"SPOCK_EMU_REVERSE": "1"}, True),

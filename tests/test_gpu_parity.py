@@ -109,10 +109,11 @@ def test_cp_solve_matches_oracle(S, O, models, name, tol, verbose):
 
 
 @pytest.mark.parametrize("name", ["per_node_dense_costs", "shared_dense_costs", "per_node_costs_large_nx", "soc_risk_cone",
-                                  "two_stage_tree", "d4_tree"])
+                                  "two_stage_tree", "d4_tree", "nonuniform_avar", "nonuniform_avar_large_nx", "tv_risk", "nonpos_cone"])
 def test_variants_match_oracle(S, O, name):
     """Less-travelled kernel paths on the GPU: per-node and dense cost matrices, a second-order part in the risk cone,
-    a two-stage tree, branching factor 4 -- operators and a whole CP solve against the oracle."""
+    a two-stage tree, branching factor 4, one risk measure per node (risk_measures.jl:127-136), the total-variation risk
+    measure (:138-147), a Nonpositives sub-cone (:29-34) -- operators and a whole CP solve against the oracle."""
     from test_emu_driver import _variant_specs
     specs, kw = _variant_specs(S, name)
     flat = S.flatten_problem(*specs)
