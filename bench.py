@@ -52,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="problem instances per GPU (4.4 MB of state each)")
+    ap.add_argument("--batch", type=int, default=2048, help="problem instances per GPU (4.4 MB of state each; 2048 = 32 tiles of 64 lanes)")
     ap.add_argument("--iters", type=int, default=96, help="CP iterations per step (rounded up to a multiple of 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
@@ -222,15 +222,23 @@ def main(argv=None):
                     traffic = k["hbm_bytes_per_launch_corrected"]; traffic_raw = k.get("hbm_bytes_per_launch_raw")
                 break
         kname = {"sub_a": "SUB_A", "sub_b": "SUB_BA" if fused else "SUB_B", "crown": "CROWN", "full": "FULL"}[dom]
-        roofline = {"bound": "hbm", "kernel": f"spock {'interleaved ' if getattr(model.sizes, 'interleaved', 0) else ''}group kernel, mode {kname}",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_raw": traffic_raw, "algorithmic_bytes_per_launch": dom_bytes,
-                    "necessary_bytes_per_launch": nec,
-                    "frac_necessary": round(nec / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if nec else None,
+        ilv = bool(getattr(model.sizes, "interleaved", 0))
+        # `achieved` / `frac`: bytes the kernel must move (entry-by-entry count) over its measured duration.
+        # SURVEY 8d's model counts the streams of an UNFUSED implementation (6 nz + 5 nv + 2 (n nx + nn nu) per iteration): the
+        # fused kernel never moves those bytes, so a rate computed on them is not a bandwidth (it would exceed the HBM peak);
+        # it is kept as survey_8d_* for comparison with round 1.
+        bytes_used = nec if nec else dom_bytes
+        ach = bytes_used / (dom_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": f"spock {'element-major ' if ilv else ''}group kernel, mode {kname}",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_raw": traffic_raw,
+                    "bytes_model": "necessary bytes of the fused kernel (reads z, v, zbar's s/tau/y, d; writes zbar, vbar, d)" if nec else "SURVEY 8d",
+                    "bytes_per_launch": bytes_used,
                     "frac_measured": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "survey_8d_bytes_per_launch": dom_bytes, "survey_8d_rate_GBps": round(achieved, 1),
                     "avg_launch_ms": round(dom_ms, 5), "launches_timed": prof[dom][1], "lib_sha16": fp,
                     "all_kernels_avg_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1]},
-                    "whole_iteration_frac": round(B * bytes_["cp_iteration"] * n_gpus / (elapsed / (M * args.steps)) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4)}
+                    "whole_iteration_frac": round(B * necessary_bytes(flat) * n_gpus / (elapsed / (M * args.steps)) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4)}
     model.close()
 
     out = {"metric": "Spock (Chambolle-Pock) iterations/sec on the server_heat tree", "value": round(value, 1),
@@ -286,6 +294,13 @@ def main(argv=None):
                                              f"(the reference is Julia; no Julia toolchain exists on this box)"}
             # the same with every host core busy: one independent oracle process per core (instances are independent)
             ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:   # a container's CPU share (cgroup v2 cpu.max) is what can actually run at once
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    ncore = max(1, min(ncore, int(float(q) / float(per))))
+            except Exception:
+                pass
+            ncore = min(ncore, 64)
             kk = max(20, k // 4)
             code = ("import sys,time,numpy as np;sys.path.insert(0,%r);import spock_jl_amd as S;from oracle import oracle as O;"
                     "f=S.flatten_problem(*S.get_server_heat_specs(%d,5,2,nu=2));o=O.Oracle(f,O.CP);o.solve(np.full(5,.1),tol=0.,max_iter=5);"

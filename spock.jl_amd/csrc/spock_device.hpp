@@ -58,7 +58,7 @@ struct StaticDims {
     static constexpr int MAXNX = NX, MAXNU = NU, MAXD = D, MAXNY = NY, MAXM = NY + 2 * D, UNR = 128;
     static constexpr bool DIAG = (CM == CM_SHARED_DIAG), SHARED = (CM != CM_GENERAL);
     static constexpr bool REGROWS = (NX <= 8 && NU <= 8);   // register-resident team sweep available
-    static constexpr bool TEAMLOCAL = false;
+    static constexpr bool TEAMLOCAL = false, MFMA_SWEEP = false;
     SPK_DEV explicit StaticDims(const Dims &) {}
     SPK_DEV constexpr int nx() const { return NX; }
     SPK_DEV constexpr int nu() const { return NU; }
@@ -66,12 +66,14 @@ struct StaticDims {
     SPK_DEV constexpr int ny() const { return NY; }
 };
 // TL: lane-team node-local phases (spock_team_local.hpp) instead of the per-thread ones: no per-thread vectors at all
-template <int CM, bool TL = false>
+// MF: the sweep levels run on the matrix cores (bwd_level_mfma / fwd_level_mfma; nx = 64, nu = 16, d = 2).  A policy of its
+// own: the fragment registers of those levels must not set the register allocation of the other shapes' kernels.
+template <int CM, bool TL = false, bool MF = false>
 struct DynDims {
     static constexpr int MAXNX = TL ? 1 : kDynMaxNx, MAXNU = TL ? 1 : kDynMaxNu, MAXD = kDynMaxD, MAXNY = TL ? 1 : kDynMaxNy,
                          MAXM = TL ? 1 : kDynMaxNy + 2 * kDynMaxD, UNR = 1;
     static constexpr bool DIAG = (CM == CM_SHARED_DIAG), SHARED = (CM != CM_GENERAL);
-    static constexpr bool REGROWS = false, TEAMLOCAL = TL;
+    static constexpr bool REGROWS = false, TEAMLOCAL = TL, MFMA_SWEEP = MF;
     int nx_, nu_, d_, ny_;
     SPK_DEV explicit DynDims(const Dims &dm) : nx_(dm.nx), nu_(dm.nu), d_(dm.d), ny_(dm.ny) {}
     SPK_DEV int nx() const { return nx_; }

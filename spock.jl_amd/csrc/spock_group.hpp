@@ -141,7 +141,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     const int team = sweeping ? a.team : 0;
 #ifndef SPOCK_HOST_EMU
     // sweep levels as matrix products on the matrix cores (spock_device.hpp: bwd_level_mfma) when the blocks fill 16 x 16 tiles
-    const bool use_mfma = team > 0 && !(P::REGROWS && a.team_reg) && mfma_sweep_applies(p.nx(), p.nu(), p.d()) && !a.no_mfma;
+    const bool use_mfma = P::MFMA_SWEEP && team > 0 && mfma_sweep_applies(p.nx(), p.nu(), p.d());
 #endif
     const int nl_grp = group_threads_dev(p.d(), stages);          // non-leaf nodes of this group
     int ngl_grp = 1;                                               // leaves of this group
@@ -286,8 +286,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 } else {
                     const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
 #ifndef SPOCK_HOST_EMU
-                    if (use_mfma) x.each([&](int tid, TState<P> &) { bwd_level_mfma<64, 16, 2>(p, dm, SW, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
-                    else
+                    if constexpr (P::MFMA_SWEEP) { if (use_mfma) { x.each([&](int tid, TState<P> &) { bwd_level_mfma<64, 16, 2>(p, dm, SW, lfirst, cnt, l == stages - 2, tid, nthr, tl); }); } }
+                    if (!use_mfma)
 #endif
                     x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 }
@@ -371,8 +371,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 } else {
                     const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
 #ifndef SPOCK_HOST_EMU
-                    if (use_mfma) x.each([&](int tid, TState<P> &) { fwd_level_mfma<64, 16, 2>(p, dm, SW, gB, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
-                    else
+                    if constexpr (P::MFMA_SWEEP) { if (use_mfma) { x.each([&](int tid, TState<P> &) { fwd_level_mfma<64, 16, 2>(p, dm, SW, gB, lfirst, cnt, l == stages - 2, tid, nthr, tl); }); } }
+                    if (!use_mfma)
 #endif
                     x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, gB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 }

@@ -116,7 +116,6 @@ struct KArgs {
     int cchunk, n_cchunks;      // crown nodes per workgroup of the node-local crown phases, number of such workgroups
     int want_xi;                // element-major regime: LOG-mode CP (combined residual xi, cp.jl:83-86) selects the kernel variant
     int grp_level;              // element-major regime, I_UP / I_DOWN: the layer of mid groups this launch works on
-    int no_mfma;                // lane-team sweeps: keep the scalar level kernels (SPOCK_AMD_NO_MFMA=1, for comparisons)
     int tile0, n_tiles;         // element-major regime: the launch covers tiles tile0 .. tile0 + n_tiles - 1 (n_tiles 0 = all)
 };
 

@@ -108,8 +108,6 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
     // instances); with a handful of workgroups the copy is pure latency in front of the sweep (+3 us per kernel)
     bool stage = g.lds_mats && ((long)a.batch * g.grid_x >= 1024 || g.team);
     if (const char *e = std::getenv("SPOCK_AMD_LDS_MATS")) stage = g.lds_mats && e[0] == '1';
-    static const bool no_mfma = std::getenv("SPOCK_AMD_NO_MFMA") != nullptr;
-    a.no_mfma = no_mfma ? 1 : 0;
     a.lds_mats = stage ? 1 : 0; a.team = g.team; a.team_reg = g.team_reg; a.ex_doubles = g.ex_doubles;
     a.xl_global = (g.team && g.xl_global && a.xlbuf) ? 1 : 0; a.xl_stride = g.xl_stride;
     if (g.team && g.xl_global && !a.xlbuf) return (int)hipErrorInvalidValue;
@@ -177,7 +175,11 @@ int launch_group(int mode, const KArgs &a, void *stream) {
                              : launch_variant<StaticDims<a_, b_, c_, e_, 0>>(mode, a, st);
     SPOCK_STATIC_SHAPES(X)
 #undef X
-    if (cm == 2 && launch_geometry(mode == MODE_FINALIZE ? MODE_CROWN : mode, dm, a.batch).team_local) return launch_variant<DynDims<2, true>>(mode, a, st);
+    if (cm == 2 && launch_geometry(mode == MODE_FINALIZE ? MODE_CROWN : mode, dm, a.batch).team_local) {
+        static const bool no_mfma = std::getenv("SPOCK_AMD_NO_MFMA") != nullptr;
+        if (dm.nx == 64 && dm.nu == 16 && dm.d == 2 && !no_mfma) return launch_variant<DynDims<2, true, true>>(mode, a, st);   // MFMA sweep levels
+        return launch_variant<DynDims<2, true>>(mode, a, st);
+    }
     return cm == 2 ? launch_variant<DynDims<2>>(mode, a, st) : cm == 1 ? launch_variant<DynDims<1>>(mode, a, st) : launch_variant<DynDims<0>>(mode, a, st);
 }
 
