@@ -40,10 +40,13 @@ SPK_DEV int spk_uniform(int x) { return x; }
 SPK_DEV int spk_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }   // wave-uniform by construction: tell the compiler
 #endif
 
-#ifdef SPOCK_ILV_NO_FUSE_A   // experiment builds: phase A of the bottom level re-reads zbar / vbar from memory
-constexpr bool kFuseNextA = false;
-#else
+// Phase A of the NEXT iteration gathered from phase B's registers on the bottom level (ANext) instead of re-read from memory.
+// Measured on MI355X (batch 2048): same kernel time, but the 26 extra live doubles spill (808 B of scratch per lane) and the raw
+// HBM traffic goes UP (FETCH + WRITE 9.3 GB against 8.7 GB per launch).  Off by default; -DSPOCK_ILV_FUSE_A builds it.
+#ifdef SPOCK_ILV_FUSE_A
 constexpr bool kFuseNextA = true;
+#else
+constexpr bool kFuseNextA = false;
 #endif
 
 template <class P>

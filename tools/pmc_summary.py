@@ -16,7 +16,14 @@ os.makedirs(dst, exist_ok=True)
 MODES = {"1": "sub_a", "2": "crown", "3": "sub_b", "5": "sub_ba", "0": "full"}
 
 
+IMODES = {"1": "sub_a", "2": "crown_top", "5": "sub_ba", "9": "crown_a", "10": "crown_up", "11": "crown_down", "4": "finalize"}
+
+
 def kind(name):
+    if "spock_igroup_kernel" in name:      # element-major regime: spock_igroup_kernel<StaticDims<...>, MODE, WX>
+        import re
+        m = re.search(r">,\s*(\d+),\s*(true|false)>", name)
+        return IMODES.get(m.group(1)) if m else None
     if "spock_group_kernel" not in name:
         return None
     m = name.rsplit(",", 1)[-1].strip().split(">")[0].strip()
@@ -25,8 +32,10 @@ def kind(name):
 
 newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)   # gpurun_out/ accumulates earlier runs
 shutil.copy(newest(os.path.join(src, "stats", "**", "*kernel_stats.csv")), os.path.join(dst, f"bench_b{B}_kernel_stats.csv"))
-out = {"config": f"bench.py --batch {B} (server_heat nx=5 nu=2 d=2 N=13), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes",
-       "kernels": {}, "batch": B}
+import hashlib
+_h = hashlib.sha256(open(os.path.join(ROOT, "spock.jl_amd", "libspock_amd.so"), "rb").read()).hexdigest()[:16]
+out = {"config": f"SPOCK_AMD_ILV_TGROUPS=1 bench.py --batch {B} (server_heat nx=5 nu=2 d=2 N=13), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes",
+       "kernels": {}, "batch": B, "lib_sha16": _h}
 for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     f = newest(os.path.join(src, sub, "**", "*counter_collection.csv"))
     rows = list(csv.DictReader(open(f)))
