@@ -188,6 +188,10 @@ int spock_debug_stamps(spock_handle_t h, uint64_t *out);
 
 const char *spock_last_error(void);
 int spock_version(void);
+/* bytes of the device path's arithmetic / storage type: 8 in libspock_amd.so (the reference is Float64 only, src/model.jl:304-307),
+ * 4 in libspock_amd_f32.so, the same sources built in single precision for BASELINE config 5's tolerance study.  The ABI is
+ * double in both; control blocks, residual reductions and the build step stay double. */
+int spock_real_size(void);
 
 #ifdef __cplusplus
 }

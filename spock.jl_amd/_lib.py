@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libspock_amd.so")
+F32_LIB = os.path.join(_HERE, "libspock_amd_f32.so")      # the same sources built with real = float (fp32 tolerance study)
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_BUILD = 0, 1, 2, 3, 4
 CONVERGED, MAX_ITER, NAN_STATUS = 0, 1, 2
@@ -72,6 +73,7 @@ SYMBOLS = {
     "spock_debug_stamps": (C.c_int, [_P, _P]),
     "spock_last_error": (C.c_char_p, []),
     "spock_version": (C.c_int, []),
+    "spock_real_size": (C.c_int, []),
 }
 
 _cache = {}

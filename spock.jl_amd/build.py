@@ -71,5 +71,26 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, tm
     return OUT
 
 
+OUT_F32 = os.path.join(HERE, "libspock_amd_f32.so")
+
+
+def build_f32(force: bool = False, verbose: bool = False) -> str:
+    """The fp32 variant (BASELINE config 5's tolerance study): the same sources with `real` = float and single-precision
+    literals in the kernel translation units; compile-time shapes narrowed to the benchmark's (the run-time-dimension kernels
+    cover everything else).  Same C ABI (double at the boundary)."""
+    global OUT
+    keep, keep_defs = OUT, os.environ.get("SPOCK_BUILD_DEFS")
+    os.environ["SPOCK_BUILD_DEFS"] = "-DSPOCK_REAL=float -cl-single-precision-constant -DSPOCK_STATIC_SHAPES(X)=X(5,2,2,5)"
+    try:
+        return build(force=force, verbose=verbose, out=OUT_F32, tmp_name="build_f32")
+    finally:
+        OUT = keep
+        if keep_defs is None:
+            os.environ.pop("SPOCK_BUILD_DEFS", None)
+        else:
+            os.environ["SPOCK_BUILD_DEFS"] = keep_defs
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_f32(force=True, verbose=True))

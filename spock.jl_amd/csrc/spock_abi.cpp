@@ -39,27 +39,29 @@ struct spock_handle_s {
     void *graph_log = nullptr;   // element-major CP: LOG-mode solves run another kernel variant (KArgs::want_xi), hence another graph
     int want_xi = 0;
     // device memory
-    double *d_mats = nullptr, *d_z[3] = {nullptr, nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}, *d_v2x = nullptr;
+    real *d_mats = nullptr, *d_z[3] = {nullptr, nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}, *d_v2x = nullptr;
     bool lat_regime = false;   // few workgroups in flight (register-resident sweep): SUB_B runs as MODE_SUB_B_LAT
     bool sp_fused = false;   // SP: the inner products with the residuals come out of phase B instead of out of LOP kernels
     bool fused = false;   // CP iteration = CROWN + SUB_BA (after one SUB_A) instead of SUB_A + CROWN + SUB_B
-    double *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_partials = nullptr, *d_x0 = nullptr, *d_hist = nullptr;
-    double *d_xlbuf = nullptr;
+    real *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_x0 = nullptr, *d_xlbuf = nullptr;
+    double *d_partials = nullptr, *d_hist = nullptr;   // residual maxima / sums and the residual log stay double
     // element-major batched regime (spock_igroup.hpp): the iterate as [element][bp]; d_z / d_v then serve as instance-major
     // staging buffers of the API (get / set state)
     bool ilv = false;
     long bpad = 0;   // batch rounded up to a multiple of 64
-    double *i_z[3] = {nullptr, nullptr, nullptr}, *i_v[2] = {nullptr, nullptr}, *i_cq = nullptr;
+    real *i_z[3] = {nullptr, nullptr, nullptr}, *i_v[2] = {nullptr, nullptr}, *i_cq = nullptr;
     bool stage_valid = false;   // d_z[0] / d_v[0] hold the instance-major copy of the current state
     Ctl *d_ctl = nullptr;
     unsigned long long *d_dbg = nullptr;
     int hist_cap = 0;
     // single-instance buffers of the operator-level entry points
-    double *o_z[2] = {nullptr, nullptr}, *o_v[2] = {nullptr, nullptr}, *o_dbuf = nullptr, *o_qroot = nullptr,
-           *o_cbuf = nullptr, *o_partials = nullptr, *o_x0 = nullptr;
+    real *o_z[2] = {nullptr, nullptr}, *o_v[2] = {nullptr, nullptr}, *o_dbuf = nullptr, *o_qroot = nullptr,
+         *o_cbuf = nullptr, *o_x0 = nullptr;
+    double *o_partials = nullptr;
     Ctl *o_ctl = nullptr;
     // SP (SuperMann) state: ten [batch][nz+nv] vectors, the circular Anderson buffers, per-instance scalars
-    double *s_vec[10] = {nullptr}, *s_MP = nullptr, *s_Q = nullptr, *s_partF = nullptr, *s_partL = nullptr;
+    real *s_vec[10] = {nullptr}, *s_MP = nullptr, *s_Q = nullptr;
+    double *s_partF = nullptr, *s_partL = nullptr;
     SpCtl *s_ctl = nullptr;
     std::vector<SpCtl> h_sp;
     std::vector<Ctl> h_ctl;
@@ -96,6 +98,25 @@ int dev_alloc(spock_handle_s *h, T **p, size_t count) {
     h->allocs.push_back(q);
     *p = (T *)q;
     return rt::dzero(q, count * sizeof(T), h->stream);
+}
+
+// The C ABI is double; the device path computes and stores in `real` (double in libspock_amd.so, float in libspock_amd_f32.so).
+// up / down move `n` elements across the boundary, converting on the host when the two differ.
+int up(spock_handle_s *h, real *dst, const double *src, size_t n) {
+    if (kRealIsDouble) return rt::h2d(dst, src, n * sizeof(real), h->stream);
+    std::vector<real> tmp(n);
+    for (size_t k = 0; k < n; ++k) tmp[k] = (real)src[k];
+    int e = rt::h2d(dst, tmp.data(), n * sizeof(real), h->stream);
+    if (!e) e = rt::sync(h->stream);   // tmp must outlive the copy
+    return e;
+}
+int down(spock_handle_s *h, double *dst, const real *src, size_t n) {
+    if (kRealIsDouble) return rt::d2h(dst, src, n * sizeof(real), h->stream);
+    std::vector<real> tmp(n);
+    int e = rt::d2h(tmp.data(), src, n * sizeof(real), h->stream);
+    if (!e) e = rt::sync(h->stream);
+    for (size_t k = 0; k < n && !e; ++k) dst[k] = (double)tmp[k];
+    return e;
 }
 
 KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
@@ -259,8 +280,8 @@ int time_cp_sequences(spock_handle_s *h) {
         }
     if (e) return e;
     h->fused = best[1] <= best[0];
-    for (int k = 0; k < 3 && !e; ++k) e = rt::dzero(h->d_z[k], B * dm.nz * sizeof(double), h->stream);
-    for (int k = 0; k < 2 && !e; ++k) e = rt::dzero(h->d_v[k], B * dm.nv * sizeof(double), h->stream);
+    for (int k = 0; k < 3 && !e; ++k) e = rt::dzero(h->d_z[k], B * dm.nz * sizeof(real), h->stream);
+    for (int k = 0; k < 2 && !e; ++k) e = rt::dzero(h->d_v[k], B * dm.nv * sizeof(real), h->stream);
     for (auto &x : cs) x.done = 1;
     if (!e) e = rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream);
     if (!e) e = rt::sync(h->stream);
@@ -294,12 +315,12 @@ int run_op(spock_handle_s *h, const double *z_in, const double *v_in, const doub
     if (v_in) RTCHECK(rt::h2d(h->o_v[0], v_in, bv, h->stream)); else RTCHECK(rt::dzero(h->o_v[0], bv, h->stream));
     if (zbar_in) RTCHECK(rt::h2d(h->o_z[1], zbar_in, bz, h->stream)); else RTCHECK(rt::dzero(h->o_z[1], bz, h->stream));
     RTCHECK(rt::dzero(h->o_v[1], bv, h->stream));
-    if (x0) RTCHECK(rt::h2d(h->o_x0, x0, sizeof(double) * dm.nx, h->stream)); else RTCHECK(rt::dzero(h->o_x0, sizeof(double) * dm.nx, h->stream));
+    if (x0) RTCHECK(rt::h2d(h->o_x0, x0, sizeof(real) * dm.nx, h->stream)); else RTCHECK(rt::dzero(h->o_x0, sizeof(real) * dm.nx, h->stream));
     Ctl c = fresh_ctl(h, gamma, sigma, 0., SPOCK_SILENT);
     RTCHECK(rt::h2d(h->o_ctl, &c, sizeof(Ctl), h->stream));
     RTCHECK(launch_iteration(h, true, 0, flags | F_NO_CTL, phase_a, phase_b));
-    if (z_out) RTCHECK(rt::d2h(z_out, h->o_z[1], bz, h->stream));
-    if (v_out) RTCHECK(rt::d2h(v_out, h->o_v[1], bv, h->stream));
+    if (z_out) RTCHECK(down(h, z_out, h->o_z[1], dm.nz));
+    if (v_out) RTCHECK(down(h, v_out, h->o_v[1], dm.nv));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
 }
@@ -325,7 +346,7 @@ SpArgs make_sp_args(spock_handle_s *h, int op) {
 }
 
 // T(in) -> out on the concatenated z|v vectors with the CP kernels (no CP termination logic: F_SP)
-int launch_sp_T(spock_handle_s *h, double *in, double *out, int sp_mode = 0, const double *dir = nullptr) {
+int launch_sp_T(spock_handle_s *h, real *in, real *out, int sp_mode = 0, const real *dir = nullptr) {
     const Dims &dm = h->bp.dm;
     KArgs a = make_args(h, false, 0, F_SP);
     a.sp_mode = h->sp_fused ? sp_mode : 0; a.dir = dir;
@@ -362,12 +383,13 @@ int launch_sp_iteration(spock_handle_s *h) {
 int sp_init_state(spock_handle_s *h) {
     const Dims &dm = h->bp.dm;
     const size_t B = (size_t)h->batch, nr = (size_t)dm.nz + dm.nv;
-    for (int k = 0; k < 10; ++k) { int e = rt::dzero(h->s_vec[k], B * nr * sizeof(double), h->stream); if (e) return e; }
+    for (int k = 0; k < 10; ++k) { int e = rt::dzero(h->s_vec[k], B * nr * sizeof(real), h->stream); if (e) return e; }
     std::vector<double> ones(B * nr, 1.0);
-    int e = rt::h2d(h->s_vec[SV_ZOLD], ones.data(), B * nr * sizeof(double), h->stream);
-    if (!e) e = rt::h2d(h->s_vec[SV_ROLD], ones.data(), B * nr * sizeof(double), h->stream);
-    if (!e) e = rt::dzero(h->s_MP, B * 3 * nr * sizeof(double), h->stream);
-    if (!e) e = rt::dzero(h->s_Q, B * 3 * nr * sizeof(double), h->stream);
+    int e = up(h, h->s_vec[SV_ZOLD], ones.data(), B * nr);
+    if (!e) e = up(h, h->s_vec[SV_ROLD], ones.data(), B * nr);
+    if (!e) e = rt::sync(h->stream);
+    if (!e) e = rt::dzero(h->s_MP, B * 3 * nr * sizeof(real), h->stream);
+    if (!e) e = rt::dzero(h->s_Q, B * 3 * nr * sizeof(real), h->stream);
     SpCtl c;
     std::memset(&c, 0, sizeof(c));
     c.R[0] = c.R[4] = c.R[8] = 1.;
@@ -382,11 +404,11 @@ int sp_solve(spock_handle_s *h, const double *x0, double tol, int verbose, const
              double gamma, double sigma, spock_result_t *results) {
     const Dims &dm = h->bp.dm;
     const size_t B = (size_t)h->batch, nr = (size_t)dm.nz + dm.nv;
-    if (x0) RTCHECK(rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream));   // NULL: x0 is already on the device (MPC loop)
+    if (x0) RTCHECK(up(h, h->d_x0, x0, B * dm.nx));   // NULL: x0 is already on the device (MPC loop)
     if (z0) {
         for (size_t b = 0; b < B; ++b) {
-            RTCHECK(rt::h2d(h->s_vec[SV_Z] + b * nr, z0 + b * dm.nz, sizeof(double) * dm.nz, h->stream));
-            RTCHECK(rt::h2d(h->s_vec[SV_Z] + b * nr + dm.nz, v0 + b * dm.nv, sizeof(double) * dm.nv, h->stream));
+            RTCHECK(up(h, h->s_vec[SV_Z] + b * nr, z0 + b * dm.nz, dm.nz));
+            RTCHECK(up(h, h->s_vec[SV_Z] + b * nr + dm.nz, v0 + b * dm.nv, dm.nv));
         }
     }
     h->h_ctl.assign(B, fresh_ctl(h, gamma, sigma, tol, verbose));
@@ -445,6 +467,7 @@ extern "C" {
 
 const char *spock_last_error(void) { return g_err.c_str(); }
 int spock_version(void) { return SPOCK_AMD_VERSION; }
+int spock_real_size(void) { return (int)sizeof(real); }
 
 int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handle_t *out) {
     if (!p || !out) return fail(SPOCK_ERR_BAD_ARG, "problem and out must not be NULL");
@@ -554,7 +577,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     if ((e = rt::event_create(&h->ev0)) || (e = rt::event_create(&h->ev1))) return bail(e, "hipEventCreate");
     const size_t B = (size_t)h->batch;
     if ((e = dev_alloc(h, &h->d_mats, h->bp.mats.size()))) return bail(e, "hipMalloc(matrix pool)");
-    if ((e = rt::h2d(h->d_mats, h->bp.mats.data(), h->bp.mats.size() * sizeof(double), h->stream))) return bail(e, "upload");
+    if ((e = up(h, h->d_mats, h->bp.mats.data(), h->bp.mats.size()))) return bail(e, "upload");
     const size_t W = h->ilv ? (size_t)h->bpad : B;   // columns of the per-instance work arrays
     if (alg == SPOCK_ALG_CP && h->ilv) {
         if ((e = dev_alloc(h, &h->d_z[0], B * dm.nz)) || (e = dev_alloc(h, &h->d_v[0], B * dm.nv))) return bail(e, "hipMalloc(staging)");
@@ -665,7 +688,7 @@ int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const 
     for (size_t k = 0; k < B * (size_t)steps; ++k)
         if (w_seq[k] < 0 || w_seq[k] >= dm.d) return fail(SPOCK_ERR_BAD_ARG, "w_seq entries must be events in [0, d)");
     int *d_w = nullptr;
-    double *d_xt = nullptr, *d_ut = nullptr;
+    real *d_xt = nullptr, *d_ut = nullptr;
     void *pw = nullptr, *pxt = nullptr, *put = nullptr;
     auto cleanup = [&]() { if (pw) rt::dfree(pw); if (pxt) rt::dfree(pxt); if (put) rt::dfree(put); };
     {
@@ -674,11 +697,11 @@ int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const 
         if (!e) e = rt::dmalloc(&put, B * steps * dm.nu * sizeof(double));
         if (e) { cleanup(); return fail(SPOCK_ERR_HIP, std::string("hipMalloc(trajectories): ") + rt::err(e)); }
     }
-    d_w = (int *)pw; d_xt = (double *)pxt; d_ut = (double *)put;
+    d_w = (int *)pw; d_xt = (real *)pxt; d_ut = (real *)put;
     int rc = SPOCK_OK;
     do {
         int e = rt::h2d(d_w, w_seq, B * steps * sizeof(int), h->stream);
-        if (!e) e = rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream);
+        if (!e) e = up(h, h->d_x0, x0, B * dm.nx);
         if (e) { rc = fail(SPOCK_ERR_HIP, rt::err(e)); break; }
         std::vector<spock_result_t> step_res(B);
         for (int t = 0; t < steps && rc == SPOCK_OK; ++t) {
@@ -698,8 +721,8 @@ int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const 
         }
         if (rc) break;
         int e2 = 0;
-        if (x_traj) e2 = rt::d2h(x_traj, d_xt, B * (steps + 1) * dm.nx * sizeof(double), h->stream);
-        if (!e2 && u_traj) e2 = rt::d2h(u_traj, d_ut, B * steps * dm.nu * sizeof(double), h->stream);
+        if (x_traj) e2 = down(h, x_traj, d_xt, B * (steps + 1) * dm.nx);
+        if (!e2 && u_traj) e2 = down(h, u_traj, d_ut, B * steps * dm.nu);
         if (!e2) e2 = rt::sync(h->stream);
         if (e2) rc = fail(SPOCK_ERR_HIP, rt::err(e2));
     } while (0);
@@ -718,10 +741,10 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
     if (!(gamma > 0. && sigma > 0.)) return fail(SPOCK_ERR_BAD_ARG, "gamma and sigma must be positive");
 
     if (h->alg == SPOCK_ALG_SP) return sp_solve(h, x0, tol, verbose, z0, v0, gamma, sigma, results);
-    if (x0) RTCHECK(rt::h2d(h->d_x0, x0, B * dm.nx * sizeof(double), h->stream));   // NULL: x0 is already on the device
+    if (x0) RTCHECK(up(h, h->d_x0, x0, B * dm.nx));   // NULL: x0 is already on the device
     if (z0) {
-        RTCHECK(rt::h2d(h->d_z[0], z0, B * dm.nz * sizeof(double), h->stream));
-        RTCHECK(rt::h2d(h->d_v[0], v0, B * dm.nv * sizeof(double), h->stream));
+        RTCHECK(up(h, h->d_z[0], z0, B * dm.nz));
+        RTCHECK(up(h, h->d_v[0], v0, B * dm.nv));
         if (h->ilv) RTCHECK(ilv_stage_to_state(h));
     }
     h->stage_valid = false;
@@ -767,18 +790,18 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
     if (h->ilv) {
         const int rp = h->h_ctl[0].result_parity;
         if (same_parity) {
-            if (rp % 3) RTCHECK(rt::d2d(h->i_z[0], h->i_z[rp % 3], (size_t)h->bpad * dm.nz * sizeof(double), h->stream));
-            if (rp % 2) RTCHECK(rt::d2d(h->i_v[0], h->i_v[1], (size_t)h->bpad * dm.nv * sizeof(double), h->stream));
+            if (rp % 3) RTCHECK(rt::d2d(h->i_z[0], h->i_z[rp % 3], (size_t)h->bpad * dm.nz * sizeof(real), h->stream));
+            if (rp % 2) RTCHECK(rt::d2d(h->i_v[0], h->i_v[1], (size_t)h->bpad * dm.nv * sizeof(real), h->stream));
         } else RTCHECK(launch_ilv_collect(h->i_z, h->i_v, h->d_ctl, dm.nz, dm.nv, h->bpad, h->batch, h->stream));
     } else if (same_parity) {
         const int rp = h->h_ctl[0].result_parity;
-        if (rp % 3) RTCHECK(rt::d2d(h->d_z[0], h->d_z[rp % 3], B * dm.nz * sizeof(double), h->stream));
-        if (rp % 2) RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * dm.nv * sizeof(double), h->stream));
+        if (rp % 3) RTCHECK(rt::d2d(h->d_z[0], h->d_z[rp % 3], B * dm.nz * sizeof(real), h->stream));
+        if (rp % 2) RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * dm.nv * sizeof(real), h->stream));
     }
     for (size_t b = 0; b < B; ++b) {
         const Ctl &c = h->h_ctl[b];
-        if (!h->ilv && !same_parity && c.result_parity % 3) RTCHECK(rt::d2d(h->d_z[0] + b * dm.nz, h->d_z[c.result_parity % 3] + b * dm.nz, sizeof(double) * dm.nz, h->stream));
-        if (!h->ilv && !same_parity && c.result_parity % 2) RTCHECK(rt::d2d(h->d_v[0] + b * dm.nv, h->d_v[1] + b * dm.nv, sizeof(double) * dm.nv, h->stream));
+        if (!h->ilv && !same_parity && c.result_parity % 3) RTCHECK(rt::d2d(h->d_z[0] + b * dm.nz, h->d_z[c.result_parity % 3] + b * dm.nz, sizeof(real) * dm.nz, h->stream));
+        if (!h->ilv && !same_parity && c.result_parity % 2) RTCHECK(rt::d2d(h->d_v[0] + b * dm.nv, h->d_v[1] + b * dm.nv, sizeof(real) * dm.nv, h->stream));
         if (c.evals > evals) evals = c.evals;
         if (results) {
             spock_result_t &r = results[b];
@@ -798,12 +821,12 @@ int spock_get_z(spock_handle_t h, double *z_out) {
     if (h->alg == SPOCK_ALG_SP) {
         const size_t nr = (size_t)h->bp.dm.nz + h->bp.dm.nv;
         for (int b = 0; b < h->batch; ++b)
-            RTCHECK(rt::d2h(z_out + (size_t)b * h->bp.dm.nz, h->s_vec[0] + b * nr, sizeof(double) * h->bp.dm.nz, h->stream));
+            RTCHECK(down(h, z_out + (size_t)b * h->bp.dm.nz, h->s_vec[0] + b * nr, h->bp.dm.nz));
         RTCHECK(rt::sync(h->stream));
         return SPOCK_OK;
     }
     if (h->ilv) RTCHECK(ilv_state_to_stage(h));
-    RTCHECK(rt::d2h(z_out, h->d_z[0], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
+    RTCHECK(down(h, z_out, h->d_z[0], (size_t)h->batch * h->bp.dm.nz));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
 }
@@ -813,12 +836,12 @@ int spock_get_v(spock_handle_t h, double *v_out) {
     if (h->alg == SPOCK_ALG_SP) {
         const size_t nr = (size_t)h->bp.dm.nz + h->bp.dm.nv;
         for (int b = 0; b < h->batch; ++b)
-            RTCHECK(rt::d2h(v_out + (size_t)b * h->bp.dm.nv, h->s_vec[0] + b * nr + h->bp.dm.nz, sizeof(double) * h->bp.dm.nv, h->stream));
+            RTCHECK(down(h, v_out + (size_t)b * h->bp.dm.nv, h->s_vec[0] + b * nr + h->bp.dm.nz, h->bp.dm.nv));
         RTCHECK(rt::sync(h->stream));
         return SPOCK_OK;
     }
     if (h->ilv) RTCHECK(ilv_state_to_stage(h));
-    RTCHECK(rt::d2h(v_out, h->d_v[0], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
+    RTCHECK(down(h, v_out, h->d_v[0], (size_t)h->batch * h->bp.dm.nv));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
 }
@@ -828,14 +851,14 @@ int spock_set_state(spock_handle_t h, const double *z, const double *v) {
     if (h->alg == SPOCK_ALG_SP) {
         const size_t nr = (size_t)h->bp.dm.nz + h->bp.dm.nv;
         for (int b = 0; b < h->batch; ++b) {
-            RTCHECK(rt::h2d(h->s_vec[0] + b * nr, z + (size_t)b * h->bp.dm.nz, sizeof(double) * h->bp.dm.nz, h->stream));
-            RTCHECK(rt::h2d(h->s_vec[0] + b * nr + h->bp.dm.nz, v + (size_t)b * h->bp.dm.nv, sizeof(double) * h->bp.dm.nv, h->stream));
+            RTCHECK(up(h, h->s_vec[0] + b * nr, z + (size_t)b * h->bp.dm.nz, h->bp.dm.nz));
+            RTCHECK(up(h, h->s_vec[0] + b * nr + h->bp.dm.nz, v + (size_t)b * h->bp.dm.nv, h->bp.dm.nv));
         }
         RTCHECK(rt::sync(h->stream));
         return SPOCK_OK;
     }
-    RTCHECK(rt::h2d(h->d_z[0], z, (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
-    RTCHECK(rt::h2d(h->d_v[0], v, (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
+    RTCHECK(up(h, h->d_z[0], z, (size_t)h->batch * h->bp.dm.nz));
+    RTCHECK(up(h, h->d_v[0], v, (size_t)h->batch * h->bp.dm.nv));
     if (h->ilv) { RTCHECK(ilv_stage_to_state(h)); h->stage_valid = true; }
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
@@ -845,16 +868,16 @@ int spock_reset(spock_handle_t h) {
     DeviceGuard guard(h->device);
     if (h->alg == SPOCK_ALG_SP) { RTCHECK(sp_init_state(h)); return SPOCK_OK; }
     if (h->ilv) {
-        for (int k = 0; k < 3; ++k) RTCHECK(rt::dzero(h->i_z[k], (size_t)h->bpad * h->bp.dm.nz * sizeof(double), h->stream));
-        for (int k = 0; k < 2; ++k) RTCHECK(rt::dzero(h->i_v[k], (size_t)h->bpad * h->bp.dm.nv * sizeof(double), h->stream));
-        RTCHECK(rt::dzero(h->d_z[0], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
-        RTCHECK(rt::dzero(h->d_v[0], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
+        for (int k = 0; k < 3; ++k) RTCHECK(rt::dzero(h->i_z[k], (size_t)h->bpad * h->bp.dm.nz * sizeof(real), h->stream));
+        for (int k = 0; k < 2; ++k) RTCHECK(rt::dzero(h->i_v[k], (size_t)h->bpad * h->bp.dm.nv * sizeof(real), h->stream));
+        RTCHECK(rt::dzero(h->d_z[0], (size_t)h->batch * h->bp.dm.nz * sizeof(real), h->stream));
+        RTCHECK(rt::dzero(h->d_v[0], (size_t)h->batch * h->bp.dm.nv * sizeof(real), h->stream));
         h->stage_valid = true;
         RTCHECK(rt::sync(h->stream));
         return SPOCK_OK;
     }
-    for (int k = 0; k < 3; ++k) RTCHECK(rt::dzero(h->d_z[k], (size_t)h->batch * h->bp.dm.nz * sizeof(double), h->stream));
-    for (int k = 0; k < 2; ++k) RTCHECK(rt::dzero(h->d_v[k], (size_t)h->batch * h->bp.dm.nv * sizeof(double), h->stream));
+    for (int k = 0; k < 3; ++k) RTCHECK(rt::dzero(h->d_z[k], (size_t)h->batch * h->bp.dm.nz * sizeof(real), h->stream));
+    for (int k = 0; k < 2; ++k) RTCHECK(rt::dzero(h->d_v[k], (size_t)h->batch * h->bp.dm.nv * sizeof(real), h->stream));
     RTCHECK(rt::sync(h->stream));
     return SPOCK_OK;
 }
@@ -989,12 +1012,12 @@ int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_
     for (int q = 0; q < 4; ++q) { avg_ms[q] = cnt[q] ? sum[q] / cnt[q] : 0.; if (launches) launches[q] = cnt[q]; }
     // leave a consistent state behind: the iterate after `reps` iterations goes back to slot 0
     if (h->ilv) {
-        if (reps % 3) RTCHECK(rt::d2d(h->i_z[0], h->i_z[reps % 3], (size_t)h->bpad * h->bp.dm.nz * sizeof(double), h->stream));
-        if (reps % 2) RTCHECK(rt::d2d(h->i_v[0], h->i_v[1], (size_t)h->bpad * h->bp.dm.nv * sizeof(double), h->stream));
+        if (reps % 3) RTCHECK(rt::d2d(h->i_z[0], h->i_z[reps % 3], (size_t)h->bpad * h->bp.dm.nz * sizeof(real), h->stream));
+        if (reps % 2) RTCHECK(rt::d2d(h->i_v[0], h->i_v[1], (size_t)h->bpad * h->bp.dm.nv * sizeof(real), h->stream));
         h->stage_valid = false;
     } else {
-        if (reps % 3) RTCHECK(rt::d2d(h->d_z[0], h->d_z[reps % 3], B * h->bp.dm.nz * sizeof(double), h->stream));
-        if (reps % 2) RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * h->bp.dm.nv * sizeof(double), h->stream));
+        if (reps % 3) RTCHECK(rt::d2d(h->d_z[0], h->d_z[reps % 3], B * h->bp.dm.nz * sizeof(real), h->stream));
+        if (reps % 2) RTCHECK(rt::d2d(h->d_v[0], h->d_v[1], B * h->bp.dm.nv * sizeof(real), h->stream));
     }
     for (auto &x : cs) x.done = 1;
     RTCHECK(rt::h2d(h->d_ctl, cs.data(), B * sizeof(Ctl), h->stream));

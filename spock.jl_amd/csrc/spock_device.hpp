@@ -41,9 +41,9 @@ namespace spock {
 // SGPRs that feed v_fma_f64 directly) instead of 64 identical per-lane vector loads; per-lane (divergent)
 // indices still work and fall back to vector loads.
 #ifdef SPOCK_HOST_EMU
-typedef const double *MatPtr;
+typedef const real *MatPtr;
 #else
-typedef const __attribute__((address_space(4))) double *MatPtr;
+typedef const __attribute__((address_space(4))) real *MatPtr;
 #endif
 
 // cost-matrix mode (template parameter CM of the dimension policies)
@@ -85,10 +85,10 @@ struct DynDims {
 // lane-team node-local phases (spock_team_local.hpp): per-lane registers carried from part 1 to part 2 of a phase
 template <class P>
 struct TLReg {
-    double xb, ub;                        // A: xbar_r, ubar_r         B: x_i[r] - z (dz), see below
-    double wx, dzx, wu, dzu, wy, dzy;     // B: w = 2 zbar - z and dz = zbar - z on x_i[r], u_i[r], y_i[r]
-    double t3[P::MAXD], l3[P::MAXD], t4[P::MAXD], l4[P::MAXD];       // child blocks: pre-prox value / (L dz)
-    double t11[P::MAXD], l11[P::MAXD], t14[P::MAXD], wl[P::MAXD], dl[P::MAXD];   // leaf blocks
+    real xb, ub;                        // A: xbar_r, ubar_r         B: x_i[r] - z (dz), see below
+    real wx, dzx, wu, dzu, wy, dzy;     // B: w = 2 zbar - z and dz = zbar - z on x_i[r], u_i[r], y_i[r]
+    real t3[P::MAXD], l3[P::MAXD], t4[P::MAXD], l4[P::MAXD];       // child blocks: pre-prox value / (L dz)
+    real t11[P::MAXD], l11[P::MAXD], t14[P::MAXD], wl[P::MAXD], dl[P::MAXD];   // leaf blocks
 };
 
 constexpr int kStageRegs = 4;   // sweep inputs a thread can hold in registers while the control block is in flight
@@ -101,33 +101,34 @@ struct TState {
     bool active;
     bool kids_leaf;           // children are leaves of the TREE (this thread also owns them)
     bool kids_gleaf;          // children are leaves of the GROUP (crown: the subtree roots)
-    double xb[P::MAXNX];      // phase A: c_i = U ubar_i - xbar_i  -> x_i (after the forward sweep)
-    double ub[P::MAXNU];      // phase A: e_i = Rt^-1 ubar_i       -> u_i
-    double dd[P::MAXNU];      // d_i of the Riccati recursion
-    double xl[P::MAXD][P::MAXNX];  // leaf children: xbar_j -> x_j
-    double stg[kStageRegs];        // early-issued loads of the sweep inputs (spock_group.hpp)
+    real xb[P::MAXNX];      // phase A: c_i = U ubar_i - xbar_i  -> x_i (after the forward sweep)
+    real ub[P::MAXNU];      // phase A: e_i = Rt^-1 ubar_i       -> u_i
+    real dd[P::MAXNU];      // d_i of the Riccati recursion
+    real xl[P::MAXD][P::MAXNX];  // leaf children: xbar_j -> x_j
+    real stg[kStageRegs];        // early-issued loads of the sweep inputs (spock_group.hpp)
     TLReg<P> tlr;                  // lane-team local phases
-    double mx3[3];                 // residual maxima accumulated over the rounds of the lane-team phase B
-    double sp3[3];                 // ... and the SP inner products (tb_p2 SPM)
+    real mx3[3];                 // residual maxima accumulated over the rounds of the lane-team phase B
+    real sp3[3];                 // ... and the SP inner products (tb_p2 SPM)
     // register-resident lane-team sweep (small compile-time shapes): this thread = (node tn_li, matrix row tn_r)
     // and keeps ITS rows of the sweep matrices of its node's stage for the whole kernel
     int tn_li, tn_r, tn_lvl, tn_pos;
-    double tW[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNX : 1], tV[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNX : 1];
-    double tA[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNX : 1], tB[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNU : 1];
-    double tK[P::REGROWS ? P::MAXNX : 1];
+    real tW[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNX : 1], tV[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNX : 1];
+    real tA[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNX : 1], tB[P::REGROWS ? P::MAXD : 1][P::REGROWS ? P::MAXNU : 1];
+    real tK[P::REGROWS ? P::MAXNX : 1];
 };
 
-SPK_DEV double spk_max_nan(double m, double a) { return (a > m || a != a) ? a : m; }  // NaN-propagating max
-SPK_DEV double spk_clamp(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
+template <class T>
+SPK_DEV T spk_max_nan(T m, T a) { return (a > m || a != a) ? a : m; }  // NaN-propagating max
+SPK_DEV real spk_clamp(real x, real lo, real hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
 // event of child slot c: w = (j % d) + 1 with j = 2 + (i-1) d + c, 1-based (scenario_tree.jl:77)
 SPK_DEV int slot_event(int c, int d) { return (2 + c) % d; }
 
 // y (+)= S x for a symmetric cost square root S (n x n)
 template <class P, bool ACC, class XV>
-SPK_DEV void sym_mv(int n, MatPtr S, XV x, double *y) {
+SPK_DEV void sym_mv(int n, MatPtr S, XV x, real *y) {
     SPK_UNROLL for (int r = 0; r < n; ++r) {
-        double t;
+        real t;
         if (P::DIAG) t = S[r + r * n] * x[r];
         else {
             t = 0.;
@@ -139,16 +140,16 @@ SPK_DEV void sym_mv(int n, MatPtr S, XV x, double *y) {
 
 // (t; x) second-order-cone projection, MOI ordering t first (risk_measures.jl:47-71)
 template <int MAXLEN>
-SPK_DEV void project_soc(double *vec, int len) {
-    double t = vec[0], s = 0.;
+SPK_DEV void project_soc(real *vec, int len) {
+    real t = vec[0], s = 0.;
     for (int i = 1; i < len; ++i) s += vec[i] * vec[i];
-    double x_norm = sqrt(s);
+    real x_norm = sqrt(s);
     if (x_norm <= t) {
     } else if (x_norm <= -t) {
         for (int k = 0; k < len; ++k) vec[k] = 0.;
     } else {
-        const double t2 = (t + x_norm) / 2.;
-        const double sc = t2 / x_norm;   // the reference evaluates (t2 * vec[k]) / x_norm: same up to one rounding
+        const real t2 = (t + x_norm) / 2.;
+        const real sc = t2 / x_norm;   // the reference evaluates (t2 * vec[k]) / x_norm: same up to one rounding
         vec[0] = t2;
         for (int k = 1; k < len; ++k) vec[k] = sc * vec[k];
     }
@@ -163,26 +164,40 @@ SPK_DEV void project_soc(double *vec, int len) {
 // IVec element e of this lane's instance lives at base[e * stride] + lane, `base` wave-uniform.
 #ifdef SPOCK_HOST_EMU
 struct IVec {
-    double *base;
+    real *base;
     long stride;
     unsigned lb;
-    SPK_DEV double &operator[](long e) const { return *(double *)((char *)(base + e * stride) + lb); }
+    SPK_DEV real &operator[](long e) const { return *(real *)((char *)(base + e * stride) + lb); }
     SPK_DEV IVec operator+(long off) const { return IVec{base + off * stride, stride, lb}; }
     SPK_DEV explicit operator bool() const { return base != nullptr; }
 };
 // view of `n_elems` element rows starting at the tile's first column `base_tile`, for lane `lane`
-SPK_DEV IVec ivec_make(const double *base_tile, long stride, int lane, long) { return IVec{const_cast<double *>(base_tile), stride, (unsigned)lane * 8u}; }
+SPK_DEV IVec ivec_make(const real *base_tile, long stride, int lane, long) { return IVec{const_cast<real *>(base_tile), stride, (unsigned)lane * (unsigned)sizeof(real)}; }
 SPK_DEV IVec ivec_null() { return IVec{nullptr, 0, 0}; }
 #else
 // gfx950: buffer addressing.  address = resource base (4 SGPRs, the array's tile column) + soffset (one SGPR: the element row,
 // e * stride * 8 bytes, scalar arithmetic) + voffset (one VGPR for the whole kernel: lane * 8): no per-row vector or 64-bit
 // scalar address arithmetic at all.  Offsets are 32-bit: an array must stay below 4 GiB (checked at spock_create).
 typedef unsigned int spk_u32x2 __attribute__((ext_vector_type(2)));
+template <class T> SPK_DEV T spk_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <> SPK_DEV double spk_buf_load<double>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+template <> SPK_DEV float spk_buf_load<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <class T> SPK_DEV void spk_buf_store(T v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <> SPK_DEV void spk_buf_store<double>(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(spk_u32x2, v), r, voff, soff, 0);
+}
+template <> SPK_DEV void spk_buf_store<float>(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
 struct IBufRef {
     __amdgpu_buffer_rsrc_t r;
     unsigned voff, soff;
-    SPK_DEV operator double() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
-    SPK_DEV void operator=(double v) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(spk_u32x2, v), r, voff, soff, 0); }
+    SPK_DEV operator real() const { return spk_buf_load<real>(r, voff, soff); }
+    SPK_DEV void operator=(real v) const { spk_buf_store<real>(v, r, voff, soff); }
 };
 struct IVec {
     __amdgpu_buffer_rsrc_t r;
@@ -192,18 +207,18 @@ struct IVec {
     SPK_DEV IVec operator+(long off) const { return IVec{r, stride8, voff, soff + (unsigned)off * stride8, ok}; }
     SPK_DEV explicit operator bool() const { return ok; }
 };
-SPK_DEV IVec ivec_make(const double *base_tile, long stride, int lane, long n_elems) {
-    const unsigned long bytes = ((unsigned long)(n_elems > 0 ? n_elems - 1 : 0) * (unsigned long)stride + 64ul) * 8ul;
+SPK_DEV IVec ivec_make(const real *base_tile, long stride, int lane, long n_elems) {
+    const unsigned long bytes = ((unsigned long)(n_elems > 0 ? n_elems - 1 : 0) * (unsigned long)stride + 64ul) * sizeof(real);
     return IVec{__builtin_amdgcn_make_buffer_rsrc((void *)base_tile, 0, (int)(bytes > 0xfffffffful ? 0xfffffffful : bytes), 0x00020000),
-                (unsigned)stride * 8u, (unsigned)lane * 8u, 0u, base_tile != nullptr};
+                (unsigned)stride * (unsigned)sizeof(real), (unsigned)lane * (unsigned)sizeof(real), 0u, base_tile != nullptr};
 }
 SPK_DEV IVec ivec_null() { return IVec{__builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000), 0u, 0u, 0u, false}; }
 #endif
 typedef IVec ICVec;
 // LDS slots of the sweep: element e of this lane at p[e * 64]
 struct LVec {
-    double *p;
-    SPK_DEV double &operator[](long e) const { return p[e * 64]; }
+    real *p;
+    SPK_DEV real &operator[](long e) const { return p[e * 64]; }
     SPK_DEV LVec operator+(long off) const { return LVec{p + off * 64}; }
     SPK_DEV explicit operator bool() const { return p != nullptr; }
 };
@@ -225,11 +240,11 @@ SPK_DEV void spk_block_fence() {
 // resource: a plain maximum (one instruction) plus one FMA per entry into a `poison` accumulator that turns NaN as soon as any
 // entry is NaN or infinite (0 * x); the workgroup's maxima are replaced by NaN when it did (spock_igroup.hpp: reduce_maxima).
 template <class V>
-SPK_DEV void spk_resmax(double &m, double x, double &poison) {
+SPK_DEV void spk_resmax(real &m, real x, real &poison) {
 #ifndef SPOCK_HOST_EMU
     if constexpr (IsIlvView<V>::value) {
-        m = __builtin_fmax(m, __builtin_fabs(x));
-        poison = __builtin_fma(x, 0., poison);
+        m = fmax(m, fabs(x));
+        poison = fma(x, (real)0., poison);
         return;
     }
 #endif
@@ -239,15 +254,15 @@ SPK_DEV void spk_resmax(double &m, double x, double &poison) {
 // vbar.v2 of a node's children handed over in registers (crown chunks of the element-major fused kernel)
 template <int MAXD>
 struct V2Reg {
-    double v[MAXD];
+    real v[MAXD];
     int base;
-    SPK_DEV double operator[](int i) const {
-        double r = v[0];
+    SPK_DEV real operator[](int i) const {
+        real r = v[0];
         for (int c = 1; c < MAXD; ++c) if (i - base == c) r = v[c];
         return r;
     }
 };
-SPK_DEV bool v2x_applies(const double *p, bool kids_gleaf) { return p && kids_gleaf; }
+SPK_DEV bool v2x_applies(const real *p, bool kids_gleaf) { return p && kids_gleaf; }
 template <int MAXD>
 SPK_DEV bool v2x_applies(const V2Reg<MAXD> &, bool) { return true; }
 
@@ -277,18 +292,18 @@ SPK_DEV void init_geometry(const P &p, const Dims &dm, int tau, int root_stage, 
 // phase A, node-local:  zbar0 = (-gamma) L'v + z on the entries owned by node i, then S2, then the
 // node-local terms of the S1 recursion: c_i = U_t ubar_i - xbar_i and e_i = Rt^-1 ubar_i (spock_host.cpp).
 template <class P, class ZO>
-SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s, const double *xbar, const double *ubar, const double *vec);
+SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s, const real *xbar, const real *ubar, const real *vec);
 
 template <class P, class ZI, class VI, class ZO, class V2>
-SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, TState<P> &s, double gamma, unsigned flags, V2 v2x) {
+SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, TState<P> &s, real gamma, unsigned flags, V2 v2x) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu;
-    const double mg = -gamma;
+    const real mg = -gamma;
     const bool raw = (flags & F_RAW_LT) != 0;
-    double xbar[P::MAXNX], ubar[P::MAXNU];
+    real xbar[P::MAXNX], ubar[P::MAXNU];
     // x_i <- Gamma' v7 + sum_j sqrtQ_j v3_j  (implicit_l.jl:351-373)
     {
-        double acc[P::MAXNX];
+        real acc[P::MAXNX];
         SPK_UNROLL for (int k = 0; k < nx; ++k) acc[k] = v[dm.o7 + i * nxu + k];
         SPK_UNROLL for (int c = 0; c < d; ++c) {
             const int jn = s.c0 + c - 1;
@@ -299,7 +314,7 @@ SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, 
     spk_block_fence<ZI>();
     // u_i <- Gamma' v7 + sum_j sqrtR_j v4_j  (implicit_l.jl:399-420)
     {
-        double acc[P::MAXNU];
+        real acc[P::MAXNU];
         SPK_UNROLL for (int k = 0; k < nu; ++k) acc[k] = v[dm.o7 + i * nxu + nx + k];
         SPK_UNROLL for (int c = 0; c < d; ++c) {
             const int jn = s.c0 + c - 1;
@@ -309,13 +324,13 @@ SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, 
     }
     spk_block_fence<ZI>();
     // [y_i ; s_children ; tau_children]  (implicit_l.jl:423-448)
-    double vec[P::MAXM];
-    const double v2i = v[dm.o2 + i];
+    real vec[P::MAXM];
+    const real v2i = v[dm.o2 + i];
     const MatPtr bb = M + dm.mb + (dm.nRm > 1 ? i * ny : 0);          // rms[i].b (implicit_l.jl:427)
     SPK_UNROLL for (int k = 0; k < ny; ++k) vec[k] = mg * (v[i * ny + k] - bb[k] * v2i) + z[dm.zy + i * ny + k];
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = s.c0 + c;
-        double ls;
+        real ls;
         if (v2x_applies(v2x, s.kids_gleaf)) ls = v2x[s.pos * d + c];   // crown workgroup of the fused B+A kernel, children = subtree roots
         else if (j < dm.nn) ls = v[dm.o2 + j];
         else ls = 0.5 * v[dm.o12 + (j - dm.nn)] + 0.5 * v[dm.o13 + (j - dm.nn)];
@@ -327,7 +342,7 @@ SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, 
     if (s.kids_leaf) {
         SPK_UNROLL for (int c = 0; c < d; ++c) {
             const int j = s.c0 + c, li = j - dm.nn;
-            double t[P::MAXNX];
+            real t[P::MAXNX];
             sym_mv<P, false>(nx, M + dm.mSqQN + (P::SHARED ? 0 : li) * nx * nx, v + dm.o11 + li * nx, t);
             SPK_UNROLL for (int r = 0; r < nx; ++r) s.xl[c][r] = mg * (v[dm.o14 + li * nx + r] + t[r]) + z[dm.zx + j * nx + r];
         }
@@ -354,14 +369,14 @@ SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, 
 // second half of phase A: S2 on [y_i; s_ch; tau_ch] = vec (its part of the next zbar goes to zo), then the node-local terms of
 // the S1 recursion c_i -> s.xb, e_i -> s.ub from xbar, ubar (the leaves' xbar stays in s.xl)
 template <class P, class ZO>
-SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s, const double *xbar, const double *ubar, const double *vec) {
+SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s, const real *xbar, const real *ubar, const real *vec) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node;
     // S2: projector onto ker [E' -I -I ; F' 0 0] applied to [y_i; s_ch; tau_ch]  (implicit_l.jl:708-726)
     const int m = ny + 2 * d;
     const MatPtr LS = M + dm.mLs + (dm.nRm > 1 ? i * m * m : 0);       // ls_matrix[i] (implicit_l.jl:717)
     SPK_UNROLL for (int r = 0; r < m; ++r) {
-        double t = 0.;
+        real t = 0.;
         SPK_UNROLL for (int k = 0; k < m; ++k) t += LS[r + k * m] * vec[k];
         if (r < ny) zo[dm.zy + i * ny + r] = t;
         else if (r < ny + d) zo[dm.zs + s.c0 + (r - ny)] = t;
@@ -372,12 +387,12 @@ SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s,
     const MatPtr Ut = M + dm.mU + s.stage * nx * nu;
     const MatPtr Ri = M + dm.mRinv + s.stage * nu * nu;
     SPK_UNROLL for (int r = 0; r < nx; ++r) {
-        double t = 0.;
+        real t = 0.;
         SPK_UNROLL for (int k = 0; k < nu; ++k) t += Ut[r + k * nx] * ubar[k];
         s.xb[r] = t - xbar[r];
     }
     SPK_UNROLL for (int r = 0; r < nu; ++r) {
-        double t = 0.;
+        real t = 0.;
         SPK_UNROLL for (int k = 0; k < nu; ++k) t += Ri[r + k * nu] * ubar[k];
         s.ub[r] = t;
     }
@@ -386,9 +401,9 @@ SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s,
 // plain-pointer form (instance-major layout): the restrict qualifiers tell the compiler that the iterate it reads and the
 // one it writes do not overlap, which lets it issue the loads of a phase ahead of that phase's stores
 template <class P>
-SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
-                     const double *__restrict__ v, double *__restrict__ zo, TState<P> &s, double gamma, unsigned flags,
-                     const double *v2x = nullptr) {
+SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const real *__restrict__ z,
+                     const real *__restrict__ v, real *__restrict__ zo, TState<P> &s, real gamma, unsigned flags,
+                     const real *v2x = nullptr) {
     a_local_g(p, dm, M, z, v, zo, s, gamma, flags, v2x);
 }
 
@@ -398,28 +413,28 @@ SPK_DEV void a_local(const P &p, const Dims &dm, MatPtr M, const double *__restr
 //   ex    : LDS exchange buffer, [group non-leaf local index][nx]
 //   qg    : global q of the group leaves when they are subtree roots (crown), else nullptr
 //   q_out : where the group root's q goes (subtree -> global), or nullptr
-//   SW    : the sweep block of stage t ([W | V | ABK | K], spock_host.cpp) -- in LDS (const double *) or in the
+//   SW    : the sweep block of stage t ([W | V | ABK | K], spock_host.cpp) -- in LDS (const real *) or in the
 //           constant-address-space pool (MatPtr)
 template <class P, class MPT, class EX, class QG, class QO>
 SPK_DEV void bwd_node(const P &p, const Dims &dm, MPT SW, int tau, EX ex, QG qg, QO q_out, TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
-    double qi[P::MAXNX], di[P::MAXNU];
+    real qi[P::MAXNX], di[P::MAXNU];
     SPK_UNROLL for (int k = 0; k < nx; ++k) qi[k] = s.xb[k];
     SPK_UNROLL for (int k = 0; k < nu; ++k) di[k] = s.ub[k];
     SPK_UNROLL for (int c = 0; c < d; ++c) {
-        double qc[P::MAXNX];
+        real qc[P::MAXNX];
         if (s.kids_leaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[k] = -s.xl[c][k]; }   // q_leaf = -xbar_leaf (:578-582)
         else if (s.kids_gleaf) { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[k] = qg[(s.pos * d + c) * nx + k]; }
         else { SPK_UNROLL for (int k = 0; k < nx; ++k) qc[k] = ex[(tau * d + 1 + c) * nx + k]; }
         const MPT W = SW + dm.sw_oW + c * nx * nx;
         const MPT V = SW + dm.sw_oV + c * nu * nx;
         SPK_UNROLL for (int r = 0; r < nx; ++r) {
-            double a = 0.;
+            real a = 0.;
             SPK_UNROLL for (int k = 0; k < nx; ++k) a += W[r + k * nx] * qc[k];
             qi[r] += a;
         }
         SPK_UNROLL for (int r = 0; r < nu; ++r) {
-            double a = 0.;
+            real a = 0.;
             SPK_UNROLL for (int k = 0; k < nx; ++k) a += V[r + k * nu] * qc[k];
             di[r] -= a;
         }
@@ -435,24 +450,24 @@ SPK_DEV void bwd_node(const P &p, const Dims &dm, MPT SW, int tau, EX ex, QG qg,
 template <class P, class MPT, class EX, class XR>
 SPK_DEV void fwd_node(const P &p, const Dims &dm, MPT SW, MPT Bm, int tau, EX ex, XR xroot, TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d();
-    double xi[P::MAXNX];
+    real xi[P::MAXNX];
     if (s.lvl == 0) { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = xroot[k]; }
     else { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = ex[tau * nx + k]; }
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const MPT Bw = Bm + slot_event(c, d) * nx * nu;
         const MPT Ab = SW + dm.sw_oABK + c * nx * nx;
         SPK_UNROLL for (int r = 0; r < nx; ++r) {
-            double a = 0., b2 = 0.;
+            real a = 0., b2 = 0.;
             SPK_UNROLL for (int k = 0; k < nx; ++k) a += Ab[r + k * nx] * xi[k];
             SPK_UNROLL for (int k = 0; k < nu; ++k) b2 += Bw[r + k * nx] * s.dd[k];
-            const double xc = a + b2;
+            const real xc = a + b2;
             if (s.kids_gleaf) s.xl[c][r] = xc;       // group leaves: kept in registers, stored by fwd_store
             else ex[(tau * d + 1 + c) * nx + r] = xc;
         }
     }
     const MPT Kt = SW + dm.sw_oK;
     SPK_UNROLL for (int r = 0; r < nu; ++r) {
-        double a = 0.;
+        real a = 0.;
         SPK_UNROLL for (int k = 0; k < nx; ++k) a += Kt[r + k * nu] * xi[k];
         s.ub[r] = a + s.dd[r];
     }
@@ -481,7 +496,7 @@ SPK_DEV void fwd_store(const P &p, const Dims &dm, ZO zo, const TState<P> &s) {
 // A tree level with cnt nodes is cnt*T work items strided over the workgroup, so the per-level critical path
 // is ~2 d nx FMAs per lane instead of ~2 d nx (nx + nu) for a single lane, and narrow levels no longer run
 // with 63 of 64 lanes masked.  Matrices come from the LDS-staged sweep block or from the pool (MPT).
-struct TeamLds { double *XQ, *ED, *UL, *XL; };
+struct TeamLds { real *XQ, *ED, *UL, *XL; };
 
 template <class P, class MPT>
 SPK_DEV void bwd_level_team(const P &p, const Dims &dm, MPT SW, int lvl_first, int cnt, bool kids_gleaf, int T,
@@ -490,9 +505,9 @@ SPK_DEV void bwd_level_team(const P &p, const Dims &dm, MPT SW, int lvl_first, i
     for (int w = tid; w < cnt * T; w += nthreads) {
         const int pos = w / T, r = w - pos * T, li = lvl_first + pos;   // local index of the node
         if (r >= nx && r >= nu) continue;
-        double q = (r < nx) ? L.XQ[li * nx + r] : 0., dd = (r < nu) ? L.ED[li * nu + r] : 0.;
+        real q = (r < nx) ? L.XQ[li * nx + r] : 0., dd = (r < nu) ? L.ED[li * nu + r] : 0.;
         for (int c = 0; c < d; ++c) {
-            const double *qc = kids_gleaf ? L.XL + (pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
+            const real *qc = kids_gleaf ? L.XL + (pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
             const MPT W = SW + dm.sw_oW + c * nx * nx;
             const MPT V = SW + dm.sw_oV + c * nu * nx;
             if (r < nx) { SPK_UNROLL4 for (int k = 0; k < nx; ++k) q += W[r + k * nx] * qc[k]; }
@@ -510,21 +525,21 @@ SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
     for (int w = tid; w < cnt * T; w += nthreads) {
         const int pos = w / T, r = w - pos * T, li = lvl_first + pos;
         if (r >= nx && r >= nu) continue;
-        const double *xi = L.XQ + li * nx, *di = L.ED + li * nu;
+        const real *xi = L.XQ + li * nx, *di = L.ED + li * nu;
         if (r < nx) {
             for (int c = 0; c < d; ++c) {
                 const MPT Bw = Bm + slot_event(c, d) * nx * nu;
                 const MPT Ab = SW + dm.sw_oABK + c * nx * nx;
-                double a = 0., b2 = 0.;
+                real a = 0., b2 = 0.;
                 SPK_UNROLL4 for (int k = 0; k < nx; ++k) a += Ab[r + k * nx] * xi[k];
                 SPK_UNROLL4 for (int k = 0; k < nu; ++k) b2 += Bw[r + k * nx] * di[k];
-                double *dst = kids_gleaf ? L.XL + (pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
+                real *dst = kids_gleaf ? L.XL + (pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
                 dst[r] = a + b2;
             }
         }
         if (r < nu) {
             const MPT Kt = SW + dm.sw_oK;
-            double a = 0.;
+            real a = 0.;
             SPK_UNROLL4 for (int k = 0; k < nx; ++k) a += Kt[r + k * nu] * xi[k];
             L.UL[li * nu + r] = a + di[r];
         }
@@ -547,13 +562,13 @@ SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
 typedef double spk_v4d __attribute__((ext_vector_type(4)));
 
 // instantiated shapes (nx, nu): BASELINE config 5
-SPK_DEV bool mfma_sweep_applies(int nx, int nu, int d) { return nx == 64 && nu == 16 && d == 2; }
+SPK_DEV bool mfma_sweep_applies(int nx, int nu, int d) { return kRealIsDouble && nx == 64 && nu == 16 && d == 2; }
 
 // One wave owns a ROW tile m of the level's product and keeps its matrix fragments (KF k-steps: one 8-byte element per lane
 // each) in registers while it runs over the level's node tiles: the fragments are fetched from L2 once per level and wave --
 // their latency (the sweep is a chain of small dependent levels) is paid once, not per node tile.
 template <int KF, class MPT>
-SPK_DEV void mfma_load_frags(double (&af)[KF], MPT Mx, long ld, int kq, int nk4, int k_base) {
+SPK_DEV void mfma_load_frags(real (&af)[KF], MPT Mx, long ld, int kq, int nk4, int k_base) {
 #pragma unroll
     for (int q = 0; q < KF; ++q) af[q] = (q < nk4) ? Mx[(long)(k_base + 4 * q + kq) * ld] : 0.;
 }
@@ -576,7 +591,7 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
         const int m = it % mt, sp = it / mt;
         const bool isq = m < mq;
         const int row0 = isq ? m * 16 : (m - mq) * 16, ld = isq ? nx : nu;
-        double af[DC][KQ];
+        real af[DC][KQ];
 #pragma unroll
         for (int c = 0; c < d; ++c)
             mfma_load_frags<KQ>(af[c], (isq ? SW + dm.sw_oW + c * nx * nx : SW + dm.sw_oV + c * nu * nx) + (row0 + j), ld, kq, KQ, 0);
@@ -587,10 +602,10 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
             spk_v4d acc = {0., 0., 0., 0.};
 #pragma unroll
             for (int c = 0; c < d; ++c) {
-                const double *qc = kids_gleaf ? L.XL + (long)(posv * d + c) * nx : L.XQ + (long)(li * d + 1 + c) * nx;
+                const real *qc = kids_gleaf ? L.XL + (long)(posv * d + c) * nx : L.XQ + (long)(li * d + 1 + c) * nx;
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
-                    const double bv = valid ? qc[4 * q + kq] : 0.;
+                    const real bv = valid ? qc[4 * q + kq] : 0.;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][q], bv, acc, 0, 0, 0);
                 }
             }
@@ -622,7 +637,7 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
         const int m = it % mt, sp = it / mt;
         const bool isx = m < d * mq;
         const int c = isx ? m / mq : 0, row0 = isx ? (m - c * mq) * 16 : (m - d * mq) * 16;
-        double af[KQ], bf[KU];
+        real af[KQ], bf[KU];
         if (isx) {
             mfma_load_frags<KQ>(af, SW + dm.sw_oABK + c * nx * nx + (row0 + j), nx, kq, KQ, 0);
             mfma_load_frags<KU>(bf, Bm + slot_event(c, d) * nx * nu + (row0 + j), nx, kq, KU, 0);
@@ -635,21 +650,21 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
             const int pos = nt * 16 + j;
             const bool valid = pos < cnt;
             const int li = lvl_first + (valid ? pos : 0), posv = valid ? pos : 0;
-            const double *xi = L.XQ + (long)li * nx, *di = L.ED + (long)li * nu;
+            const real *xi = L.XQ + (long)li * nx, *di = L.ED + (long)li * nu;
             spk_v4d acc = {0., 0., 0., 0.};
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
-                const double bv = valid ? xi[4 * q + kq] : 0.;
+                const real bv = valid ? xi[4 * q + kq] : 0.;
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bv, acc, 0, 0, 0);
             }
             if (isx) {
 #pragma unroll
                 for (int q = 0; q < KU; ++q) {
-                    const double bv = valid ? di[4 * q + kq] : 0.;
+                    const real bv = valid ? di[4 * q + kq] : 0.;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[q], bv, acc, 0, 0, 0);
                 }
                 if (valid) {
-                    double *dst = kids_gleaf ? L.XL + (long)(posv * d + c) * nx : L.XQ + (long)(li * d + 1 + c) * nx;
+                    real *dst = kids_gleaf ? L.XL + (long)(posv * d + c) * nx : L.XQ + (long)(li * d + 1 + c) * nx;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) dst[row0 + kq + 4 * reg] = acc[reg];
                 }
@@ -700,10 +715,10 @@ template <class P>
 SPK_DEV void bwd_team_reg(const P &p, int stages, const TeamLds &L, const TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), li = s.tn_li, r = s.tn_r;
     const bool kg = (s.tn_lvl == stages - 2);
-    double q = (r < nx) ? L.XQ[li * nx + r] : 0., dd = (r < nu) ? L.ED[li * nu + r] : 0.;
+    real q = (r < nx) ? L.XQ[li * nx + r] : 0., dd = (r < nu) ? L.ED[li * nu + r] : 0.;
     SPK_UNROLL for (int c = 0; c < d; ++c) {
-        const double *qc = kg ? L.XL + (s.tn_pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
-        SPK_UNROLL for (int k = 0; k < nx; ++k) { const double v = qc[k]; q += s.tW[c][k] * v; dd -= s.tV[c][k] * v; }
+        const real *qc = kg ? L.XL + (s.tn_pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
+        SPK_UNROLL for (int k = 0; k < nx; ++k) { const real v = qc[k]; q += s.tW[c][k] * v; dd -= s.tV[c][k] * v; }
     }
     if (r < nx) L.XQ[li * nx + r] = q;
     if (r < nu) L.ED[li * nu + r] = dd;
@@ -713,21 +728,21 @@ template <class P>
 SPK_DEV void fwd_team_reg(const P &p, int stages, const TeamLds &L, const TState<P> &s) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), li = s.tn_li, r = s.tn_r;
     const bool kg = (s.tn_lvl == stages - 2);
-    const double *xi = L.XQ + li * nx, *di = L.ED + li * nu;
-    double xv[P::MAXNX], dv[P::MAXNU];
+    const real *xi = L.XQ + li * nx, *di = L.ED + li * nu;
+    real xv[P::MAXNX], dv[P::MAXNU];
     SPK_UNROLL for (int k = 0; k < nx; ++k) xv[k] = xi[k];
     SPK_UNROLL for (int k = 0; k < nu; ++k) dv[k] = di[k];
     if (r < nx) {
         SPK_UNROLL for (int c = 0; c < d; ++c) {
-            double a = 0., b2 = 0.;
+            real a = 0., b2 = 0.;
             SPK_UNROLL for (int k = 0; k < nx; ++k) a += s.tA[c][k] * xv[k];
             SPK_UNROLL for (int k = 0; k < nu; ++k) b2 += s.tB[c][k] * dv[k];
-            double *dst = kg ? L.XL + (s.tn_pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
+            real *dst = kg ? L.XL + (s.tn_pos * d + c) * nx : L.XQ + (li * d + 1 + c) * nx;
             dst[r] = a + b2;
         }
     }
     if (r < nu) {
-        double a = 0.;
+        real a = 0.;
         SPK_UNROLL for (int k = 0; k < nx; ++k) a += s.tK[k] * xv[k];
         L.UL[li * nu + r] = a + dv[r];
     }
@@ -737,29 +752,29 @@ SPK_DEV void fwd_team_reg(const P &p, int stages, const TeamLds &L, const TState
 // phase B, node-local.  zb = zbar (x_i, u_i and the leaf x_j come from the thread state unless
 // F_NO_SWEEP), z/v = the input iterate, vo = vbar.  mx[0..2] accumulate |xi_1|, |xi_2|, |xi| maxima.
 struct ProxScal {
-    double sigma, inv_sigma;                     // 1/sigma: arg/sigma of prox_h_conj! as a multiplication
-    double gamma;
-    double inv_sigma_neg, inv_gamma_neg;         // -1/sigma, -1/gamma as the reference forms them (cp.jl:73-75)
+    real sigma, inv_sigma;                     // 1/sigma: arg/sigma of prox_h_conj! as a multiplication
+    real gamma;
+    real inv_sigma_neg, inv_gamma_neg;         // -1/sigma, -1/gamma as the reference forms them (cp.jl:73-75)
     bool want_xi;                                // LOG-mode CP: xi = xi_1 + L' xi_2 (cp.jl:83-86)
 };
 
 // vbar.v2 of node j alone, the same arithmetic as b_local's risk block.  The fused B+A kernel's crown workgroup needs
 // it for the subtree roots, whose own threads sit in other workgroups of the same launch.
 template <class P, class ZI, class VI, class ZB>
-SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, int j, const ProxScal &ps) {
+SPK_DEV real risk_v2_only(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, int j, const ProxScal &ps) {
     const int ny = p.ny();
     const MatPtr bb = M + dm.mb + (dm.nRm > 1 ? j * ny : 0);
-    double bw = 0.;
+    real bw = 0.;
     SPK_UNROLL for (int k = 0; k < ny; ++k) {
-        const double zbk = zb[dm.zy + j * ny + k], zk = z[dm.zy + j * ny + k];
-        const double wy = 2. * zbk + -1. * zk;
+        const real zbk = zb[dm.zy + j * ny + k], zk = z[dm.zy + j * ny + k];
+        const real wy = 2. * zbk + -1. * zk;
         bw += bb[k] * wy;
     }
-    const double zbs = zb[dm.zs + j], zs_ = z[dm.zs + j];
-    const double ws = 2. * zbs + -1. * zs_;
-    double t2 = ps.sigma * (ws - bw) + v[dm.o2 + j];
+    const real zbs = zb[dm.zs + j], zs_ = z[dm.zs + j];
+    const real ws = 2. * zbs + -1. * zs_;
+    real t2 = ps.sigma * (ws - bw) + v[dm.o2 + j];
     t2 = t2 * ps.inv_sigma;
-    const double p2 = t2 >= 0. ? t2 : 0.;
+    const real p2 = t2 >= 0. ? t2 : 0.;
     return ps.sigma * (t2 - p2);
 }
 
@@ -768,7 +783,7 @@ SPK_DEV double risk_v2_only(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB
 // entries needs nothing from memory.  ax / au accumulate (L'vbar) on x_i / u_i, vec = [y_i; s_ch; tau_ch], xl the leaves' xbar.
 template <class P>
 struct ANext {
-    double ax[P::MAXNX], au[P::MAXNU], vec[P::MAXM], xl[P::MAXD][P::MAXNX];
+    real ax[P::MAXNX], au[P::MAXNU], vec[P::MAXM], xl[P::MAXD][P::MAXNX];
 };
 
 // SPM (SP driver, spock_sp.hpp): the inner products of run_sp! that involve the residual r = (z, v) - T(z, v) of THIS
@@ -782,24 +797,24 @@ struct ANext {
 // regime, where the workgroup has idle waves during phase B, a second thread does them at the same time (spock_group.hpp).
 template <class P, int SPM, int PART, class ZI, class VI, class ZB, class VO>
 SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, VO vo, TState<P> &s,
-                       const ProxScal &ps, unsigned flags, double *mx, double *sp = nullptr, const double *dirz = nullptr,
-                       const double *dirv = nullptr, ANext<P> *an = nullptr) {
+                       const ProxScal &ps, unsigned flags, real *mx, real *sp = nullptr, const real *dirz = nullptr,
+                       const real *dirv = nullptr, ANext<P> *an = nullptr) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu;
-    const double mgn = -ps.gamma;   // (an: next phase A)
-    const double sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
+    const real mgn = -ps.gamma;   // (an: next phase A)
+    const real sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0, wx = ps.want_xi;
-    double m1 = mx[0], m2 = mx[1], m3 = mx[2];
-    double poison = IsIlvView<ZI>::value ? mx[3] : 0.;   // element-major instantiation: mx has a fourth slot (spk_resmax)
+    real m1 = mx[0], m2 = mx[1], m3 = mx[2];
+    real poison = IsIlvView<ZI>::value ? mx[3] : 0.;   // element-major instantiation: mx has a fourth slot (spk_resmax)
     constexpr bool MAIN = (PART != 2), LEAF = (PART != 1);
-    double sp_z = 0., sp_v = 0., sp_d = 0.;
-    const double gm = ps.gamma;
+    real sp_z = 0., sp_v = 0., sp_d = 0.;
+    const real gm = ps.gamma;
     // one z entry (index iz, dz, xi_1) / one v entry (index iv, dv, xi_2) of the sums above
-    auto acc_z = [&](int iz, double dz, double x1) {
+    auto acc_z = [&](int iz, real dz, real x1) {
         if (SPM >= 1) sp_z += dz * x1;
         if (SPM == 2) sp_d -= dirz[iz] * (dz - sg * (x1 - nig * dz));
     };
-    auto acc_v = [&](int iv, double dv, double x2) {
+    auto acc_v = [&](int iv, real dv, real x2) {
         if (SPM >= 1) sp_v += dv * x2;
         if (SPM == 2) sp_d -= dirv[iv] * (dv - gm * (x2 - nis * dv));
     };
@@ -813,40 +828,40 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
         }
     }
     // w = 2 zbar - z (cp.jl:23-24) and dz = zbar - z on x_i, u_i
-    double wxv[P::MAXNX], dzx[P::MAXNX], wuv[P::MAXNU], dzu[P::MAXNU];
+    real wxv[P::MAXNX], dzx[P::MAXNX], wuv[P::MAXNU], dzu[P::MAXNU];
     if (MAIN) {
         SPK_UNROLL for (int k = 0; k < nx; ++k) {
-            const double zi = z[dm.zx + i * nx + k];
+            const real zi = z[dm.zx + i * nx + k];
             wxv[k] = wz ? s.xb[k] : 2. * s.xb[k] + -1. * zi;
             dzx[k] = s.xb[k] - zi;
         }
         SPK_UNROLL for (int k = 0; k < nu; ++k) {
-            const double zi = z[dm.zu + i * nu + k];
+            const real zi = z[dm.zu + i * nu + k];
             wuv[k] = wz ? s.ub[k] : 2. * s.ub[k] + -1. * zi;
             dzu[k] = s.ub[k] - zi;
         }
     }
     // accumulators of (L' dv) and (L' xi_2) on x_i, u_i
-    double ltx[P::MAXNX], ltu[P::MAXNU], lxx[P::MAXNX], lxu[P::MAXNU];
+    real ltx[P::MAXNX], ltu[P::MAXNU], lxx[P::MAXNX], lxu[P::MAXNU];
 
     // ---- v1, v2 : risk-measure block of node i -------------------------------------------------
     if (MAIN) {
         const MatPtr bb = M + dm.mb + (dm.nRm > 1 ? i * ny : 0);      // rms[i].b (implicit_l.jl:219)
-        double wy[P::MAXNY], dzy[P::MAXNY], t1[P::MAXNY], pr[P::MAXNY];
-        double bw = 0., bdz = 0.;
+        real wy[P::MAXNY], dzy[P::MAXNY], t1[P::MAXNY], pr[P::MAXNY];
+        real bw = 0., bdz = 0.;
         SPK_UNROLL for (int k = 0; k < ny; ++k) {
-            const double zbk = zb[dm.zy + i * ny + k], zk = z[dm.zy + i * ny + k];
+            const real zbk = zb[dm.zy + i * ny + k], zk = z[dm.zy + i * ny + k];
             wy[k] = wz ? zbk : 2. * zbk + -1. * zk;
             dzy[k] = zbk - zk;
             bw += bb[k] * wy[k];
             bdz += bb[k] * dzy[k];
         }
-        const double zbs = zb[dm.zs + i], zs_ = z[dm.zs + i];
-        const double ws = wz ? zbs : 2. * zbs + -1. * zs_, dzs = zbs - zs_;
+        const real zbs = zb[dm.zs + i], zs_ = z[dm.zs + i];
+        const real ws = wz ? zbs : 2. * zbs + -1. * zs_, dzs = zbs - zs_;
         // v1 = y, v2 = s - b'y  (implicit_l.jl:208-222)
         SPK_UNROLL for (int k = 0; k < ny; ++k) t1[k] = sg * wy[k] + v[i * ny + k];
-        double t2 = sg * (ws - bw) + v[dm.o2 + i];
-        double nv2;
+        real t2 = sg * (ws - bw) + v[dm.o2 + i];
+        real nv2;
         if (noprox) {
             SPK_UNROLL for (int k = 0; k < ny; ++k) pr[k] = t1[k];
             nv2 = t2;
@@ -857,7 +872,7 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
             if (!dm.risk_has_soc) {
                 SPK_UNROLL for (int k = 0; k < ny; ++k) {
                     const int kind = (dm.elem_kind_mask >> (2 * k)) & 3;
-                    const double v0 = pr[k];
+                    const real v0 = pr[k];
                     pr[k] = kind == 0 ? 0. : (kind == 1 ? (v0 < 0. ? 0. : v0) : (kind == 2 ? (v0 > 0. ? 0. : v0) : v0));
                 }
             } else {
@@ -866,19 +881,19 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
                 int off = 0;
                 for (int cn = 0; cn < dm.n_cones; ++cn) {
                     const int kind = dm.cone_kind[cn], dim = dm.cone_dim[cn];
-                    double t = 0., ss = 0.;
+                    real t = 0., ss = 0.;
                     SPK_UNROLL for (int k = 0; k < ny; ++k) {
                         if (k == off) t = pr[k];
                         if (k > off && k < off + dim) ss += pr[k] * pr[k];
                     }
-                    const double x_norm = sqrt(ss);
+                    const real x_norm = sqrt(ss);
                     // SOC (t; x): keep | zero | scale  (risk_measures.jl:47-71)
                     const bool keep = (x_norm <= t), zero = !keep && (x_norm <= -t);
-                    const double t2 = (t + x_norm) / 2., sc = t2 / x_norm;
+                    const real t2 = (t + x_norm) / 2., sc = t2 / x_norm;
                     SPK_UNROLL for (int k = 0; k < ny; ++k) {
                         if (k < off || k >= off + dim) continue;
-                        const double v0 = pr[k];
-                        double r;
+                        const real v0 = pr[k];
+                        real r;
                         if (kind == 0) r = 0.;
                         else if (kind == 1) r = v0 < 0. ? 0. : v0;
                         else if (kind == 2) r = v0 > 0. ? 0. : v0;
@@ -891,26 +906,26 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
             }
             SPK_UNROLL for (int k = 0; k < ny; ++k) pr[k] = sg * (t1[k] - pr[k]);
             t2 = t2 * isg;
-            const double p2 = t2 >= 0. ? t2 : 0.;   // implicit_l.jl:849-851
+            const real p2 = t2 >= 0. ? t2 : 0.;   // implicit_l.jl:849-851
             nv2 = sg * (t2 - p2);
         }
-        const double dv2 = nv2 - v[dm.o2 + i];
-        const double x2 = (dzs - bdz) + nis * dv2;          // xi_2 on v2
+        const real dv2 = nv2 - v[dm.o2 + i];
+        const real x2 = (dzs - bdz) + nis * dv2;          // xi_2 on v2
         spk_resmax<ZI>(m2, x2, poison);
         acc_v(dm.o2 + i, dv2, x2);
         vo[dm.o2 + i] = nv2;
         if (an) { SPK_UNROLL for (int k = 0; k < ny; ++k) an->vec[k] = mgn * (pr[k] - bb[k] * nv2) + (wy[k] - dzy[k]); }   // zbar.y = w - dz
         SPK_UNROLL for (int k = 0; k < ny; ++k) {
-            const double dv1 = pr[k] - v[i * ny + k];
+            const real dv1 = pr[k] - v[i * ny + k];
             vo[i * ny + k] = pr[k];
-            const double x2k = dzy[k] + nis * dv1;          // xi_2 on v1
+            const real x2k = dzy[k] + nis * dv1;          // xi_2 on v1
             spk_resmax<ZI>(m2, x2k, poison);
-            const double x1k = (dv1 - bb[k] * dv2) + nig * dzy[k];   // xi_1 on y (implicit_l.jl:423-429)
+            const real x1k = (dv1 - bb[k] * dv2) + nig * dzy[k];   // xi_1 on y (implicit_l.jl:423-429)
             spk_resmax<ZI>(m1, x1k, poison);
             acc_v(i * ny + k, dv1, x2k); acc_z(dm.zy + i * ny + k, dzy[k], x1k);
             if (wx) spk_resmax<ZI>(m3, (x2k - bb[k] * x2) + x1k, poison);
         }
-        const double x1s = dv2 + nig * dzs;                 // xi_1 on s_i (implicit_l.jl:440-442)
+        const real x1s = dv2 + nig * dzs;                 // xi_1 on s_i (implicit_l.jl:440-442)
         spk_resmax<ZI>(m1, x1s, poison);
         acc_z(dm.zs + i, dzs, x1s);
         if (wx) spk_resmax<ZI>(m3, x2 + x1s, poison);
@@ -920,20 +935,20 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
     if (MAIN) {
         SPK_UNROLL for (int k = 0; k < nxu; ++k) {
             const bool isx = k < nx;
-            const double wv = isx ? wxv[k] : wuv[k - nx];
-            const double dzv = isx ? dzx[k] : dzu[k - nx];
-            const double vin = v[dm.o7 + i * nxu + k];
-            double t = sg * wv + vin, nvv;
+            const real wv = isx ? wxv[k] : wuv[k - nx];
+            const real dzv = isx ? dzx[k] : dzu[k - nx];
+            const real vin = v[dm.o7 + i * nxu + k];
+            real t = sg * wv + vin, nvv;
             if (noprox) nvv = t;
             else {
                 t = t * isg;
-                const double pj = isx ? spk_clamp(t, dm.x_min, dm.x_max) : spk_clamp(t, dm.u_min, dm.u_max);
+                const real pj = isx ? spk_clamp(t, dm.x_min, dm.x_max) : spk_clamp(t, dm.u_min, dm.u_max);
                 nvv = sg * (t - pj);
             }
             vo[dm.o7 + i * nxu + k] = nvv;
             if (an) { if (isx) an->ax[k] = nvv; else an->au[k - nx] = nvv; }
-            const double dv = nvv - vin;
-            const double x2 = dzv + nis * dv;
+            const real dv = nvv - vin;
+            const real x2 = dzv + nis * dv;
             spk_resmax<ZI>(m2, x2, poison);
             acc_v(dm.o7 + i * nxu + k, dv, x2);
             if (isx) { ltx[k] = dv; lxx[k] = x2; } else { ltu[k - nx] = dv; lxu[k - nx] = x2; }
@@ -946,10 +961,10 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
         if (MAIN) {
         const MatPtr SQ = M + dm.mSqQ + (P::SHARED ? 0 : jn) * nx * nx;
         const MatPtr SR = M + dm.mSqR + (P::SHARED ? 0 : jn) * nu * nu;
-        double tt[P::MAXNX + P::MAXNU + 2], pj[P::MAXNX + P::MAXNU + 2], lz[P::MAXNX + P::MAXNU + 2];
+        real tt[P::MAXNX + P::MAXNU + 2], pj[P::MAXNX + P::MAXNU + 2], lz[P::MAXNX + P::MAXNU + 2];
         // tt/pj ordering = the reference's workspace: [v6, v3.., v4.., v5]; lz = L dz on the same entries
-        const double zbt = zb[dm.zt + jn], zt_ = z[dm.zt + jn];
-        const double wt = wz ? zbt : 2. * zbt + -1. * zt_, dzt = zbt - zt_;
+        const real zbt = zb[dm.zt + jn], zt_ = z[dm.zt + jn];
+        const real wt = wz ? zbt : 2. * zbt + -1. * zt_, dzt = zbt - zt_;
         sym_mv<P, false>(nx, SQ, wxv, tt + 1);
         sym_mv<P, false>(nx, SQ, dzx, lz + 1);
         sym_mv<P, false>(nu, SR, wuv, tt + 1 + nx);
@@ -995,7 +1010,7 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
         sym_mv<P, true>(nu, SR, tt + 1 + nx, ltu);
         if (wx) { sym_mv<P, true>(nx, SQ, lz + 1, lxx); sym_mv<P, true>(nu, SR, lz + 1 + nx, lxu); }
         // xi_1 on tau_j: 0.5 dv5 + 0.5 dv6 - dtau/gamma  (implicit_l.jl:432-437)
-        const double x1t = (0.5 * tt[1 + nxu] + 0.5 * tt[0]) + nig * dzt;
+        const real x1t = (0.5 * tt[1 + nxu] + 0.5 * tt[0]) + nig * dzt;
         spk_resmax<ZI>(m1, x1t, poison);
         acc_z(dm.zt + jn, dzt, x1t);
         if (wx) spk_resmax<ZI>(m3, (0.5 * lz[1 + nxu] + 0.5 * lz[0]) + x1t, poison);
@@ -1006,15 +1021,15 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
         if (LEAF && s.kids_leaf) {
             const int li = j - dm.nn;
             const MatPtr SN = M + dm.mSqQN + (P::SHARED ? 0 : li) * nx * nx;
-            double wl[P::MAXNX], dl[P::MAXNX];
+            real wl[P::MAXNX], dl[P::MAXNX];
             SPK_UNROLL for (int k = 0; k < nx; ++k) {
-                const double zk = z[dm.zx + j * nx + k];
+                const real zk = z[dm.zx + j * nx + k];
                 wl[k] = wz ? s.xl[c][k] : 2. * s.xl[c][k] + -1. * zk;
                 dl[k] = s.xl[c][k] - zk;
             }
-            const double zbs = zb[dm.zs + j], zs_ = z[dm.zs + j];
-            const double ws = wz ? zbs : 2. * zbs + -1. * zs_, dzs = zbs - zs_;
-            double t3[P::MAXNX + 2], p3[P::MAXNX + 2], l3[P::MAXNX + 2];   // [v13, v11.., v12]
+            const real zbs = zb[dm.zs + j], zs_ = z[dm.zs + j];
+            const real ws = wz ? zbs : 2. * zbs + -1. * zs_, dzs = zbs - zs_;
+            real t3[P::MAXNX + 2], p3[P::MAXNX + 2], l3[P::MAXNX + 2];   // [v13, v11.., v12]
             sym_mv<P, false>(nx, SN, wl, t3 + 1);
             sym_mv<P, false>(nx, SN, dl, l3 + 1);
             t3[0] = sg * (0.5 * ws) + v[dm.o13 + li];
@@ -1037,7 +1052,7 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
             t3[0] = p3[0] - v[dm.o13 + li];
             SPK_UNROLL for (int r = 0; r < nx; ++r) { vo[dm.o11 + li * nx + r] = p3[1 + r]; t3[1 + r] = p3[1 + r] - v[dm.o11 + li * nx + r]; }
             vo[dm.o12 + li] = p3[1 + nx];
-            double q11[P::MAXNX];
+            real q11[P::MAXNX];
             if (an) {   // s_leaf and x_leaf entries of (-gamma) L'vbar + zbar (implicit_l.jl:376-396, :445-448)
                 an->vec[ny + c] = mgn * (0.5 * p3[1 + nx] + 0.5 * p3[0]) + zbs;
                 sym_mv<P, false>(nx, SN, p3 + 1, q11);
@@ -1050,25 +1065,25 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
                 acc_v(dm.o12 + li, t3[1 + nx], l3[1 + nx]);
             }
             // v14 and the x_j, s_j residuals: x_leaf = v14 + sqrtQN v11 (implicit_l.jl:376-396)
-            double a11[P::MAXNX], b11[P::MAXNX];
+            real a11[P::MAXNX], b11[P::MAXNX];
             sym_mv<P, false>(nx, SN, t3 + 1, a11);
             if (wx) sym_mv<P, false>(nx, SN, l3 + 1, b11);
             SPK_UNROLL for (int r = 0; r < nx; ++r) {
-                const double vin = v[dm.o14 + li * nx + r];
-                double t = sg * wl[r] + vin, nvv;
+                const real vin = v[dm.o14 + li * nx + r];
+                real t = sg * wl[r] + vin, nvv;
                 if (noprox) nvv = t;
                 else { t = t * isg; nvv = sg * (t - spk_clamp(t, dm.x_min, dm.x_max)); }
                 vo[dm.o14 + li * nx + r] = nvv;
                 if (an) an->xl[c][r] = mgn * (nvv + q11[r]) + s.xl[c][r];
-                const double dv = nvv - vin;
-                const double x2 = dl[r] + nis * dv;
+                const real dv = nvv - vin;
+                const real x2 = dl[r] + nis * dv;
                 spk_resmax<ZI>(m2, x2, poison);
-                const double x1 = (dv + a11[r]) + nig * dl[r];
+                const real x1 = (dv + a11[r]) + nig * dl[r];
                 spk_resmax<ZI>(m1, x1, poison);
                 acc_v(dm.o14 + li * nx + r, dv, x2); acc_z(dm.zx + j * nx + r, dl[r], x1);
                 if (wx) spk_resmax<ZI>(m3, (x2 + b11[r]) + x1, poison);
             }
-            const double x1s = (0.5 * t3[1 + nx] + 0.5 * t3[0]) + nig * dzs;   // s_leaf (implicit_l.jl:445-448)
+            const real x1s = (0.5 * t3[1 + nx] + 0.5 * t3[0]) + nig * dzs;   // s_leaf (implicit_l.jl:445-448)
             spk_resmax<ZI>(m1, x1s, poison);
             acc_z(dm.zs + j, dzs, x1s);
             if (wx) spk_resmax<ZI>(m3, (0.5 * l3[1 + nx] + 0.5 * l3[0]) + x1s, poison);
@@ -1077,13 +1092,13 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
     spk_block_fence<ZI>();
     // xi_1 (and xi) on x_i, u_i
     SPK_UNROLL for (int k = 0; k < (MAIN ? nx : 0); ++k) {
-        const double x1 = ltx[k] + nig * dzx[k];
+        const real x1 = ltx[k] + nig * dzx[k];
         spk_resmax<ZI>(m1, x1, poison);
         acc_z(dm.zx + i * nx + k, dzx[k], x1);
         if (wx) spk_resmax<ZI>(m3, lxx[k] + x1, poison);
     }
     SPK_UNROLL for (int k = 0; k < (MAIN ? nu : 0); ++k) {
-        const double x1 = ltu[k] + nig * dzu[k];
+        const real x1 = ltu[k] + nig * dzu[k];
         spk_resmax<ZI>(m1, x1, poison);
         acc_z(dm.zu + i * nu + k, dzu[k], x1);
         if (wx) spk_resmax<ZI>(m3, lxu[k] + x1, poison);
@@ -1095,19 +1110,19 @@ SPK_DEV void b_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
 }
 
 template <class P, int SPM = 0, int PART = 0>
-SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z,
-                     const double *__restrict__ v, const double *zb, double *__restrict__ vo, TState<P> &s,
-                     const ProxScal &ps, unsigned flags, double *mx, double *sp = nullptr, const double *dirz = nullptr,
-                     const double *dirv = nullptr) {
+SPK_DEV void b_local(const P &p, const Dims &dm, MatPtr M, const real *__restrict__ z,
+                     const real *__restrict__ v, const real *zb, real *__restrict__ vo, TState<P> &s,
+                     const ProxScal &ps, unsigned flags, real *mx, real *sp = nullptr, const real *dirz = nullptr,
+                     const real *dirv = nullptr) {
     b_local_g<P, SPM, PART>(p, dm, M, z, v, zb, vo, s, ps, flags, mx, sp, dirz, dirv);
 }
 
 // ------------------------------------------------------------------------------------------------
 // closed-loop step (examples/server_heat/mpc_simulation.jl:164-177): u = z[u_inds[1:nu]], x0 <- A_w x0 + B_w u.
 // One thread per instance-row; `row` in [0, nx).
-SPK_DEV double mpc_advance_row(const Dims &dm, MatPtr M, const double *z, long stride_e, const double *x0, int w, int row) {
+SPK_DEV real mpc_advance_row(const Dims &dm, MatPtr M, const real *z, long stride_e, const real *x0, int w, int row) {
     const MatPtr A = M + dm.mA + w * dm.nx * dm.nx, B = M + dm.mB + w * dm.nx * dm.nu;
-    double a = 0., b = 0.;
+    real a = 0., b = 0.;
     for (int k = 0; k < dm.nx; ++k) a += A[row + k * dm.nx] * x0[k];
     for (int k = 0; k < dm.nu; ++k) b += B[row + k * dm.nx] * z[(long)(dm.zu + k) * stride_e];
     return a + b;

@@ -103,11 +103,11 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
 
 
     const MatPtr M = (MatPtr)a.mats;
-    const double *z = a.z_in + (long)inst * a.stride_z;
-    const double *v = a.v_in + (long)inst * a.stride_v;
-    double *zo = a.z_out + (long)inst * a.stride_z;
-    double *vo = a.v_out + (long)inst * a.stride_v;
-    double *ex = x.lds();
+    const real *z = a.z_in + (long)inst * a.stride_z;
+    const real *v = a.v_in + (long)inst * a.stride_v;
+    real *zo = a.z_out + (long)inst * a.stride_z;
+    real *vo = a.v_out + (long)inst * a.stride_v;
+    real *ex = x.lds();
 
     // ---- geometry of this group
     const bool sub = (MODE == MODE_SUB_A || MODE == MODE_SUB_B || MODE == MODE_SUB_BA);
@@ -118,18 +118,18 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     const int stages = crown ? dm.t0 + 1 : (sub ? dm.sub_stages : dm.N);
     const int root_node = dm.first[root_stage] + root_pos;
     const int nxu = p.nx() + p.nu();
-    double *cb = a.cbuf ? a.cbuf + (long)inst * group_threads_dev(p.d(), dm.t0 + 1) * nxu : nullptr;
+    real *cb = a.cbuf ? a.cbuf + (long)inst * group_threads_dev(p.d(), dm.t0 + 1) * nxu : nullptr;
     x.each([&](int tid, TState<P> &s) { init_geometry(p, dm, tid, root_stage, root_pos, stages, crown, s); });
 
     // ---- stage the sweep matrices of this group's stages (and B) in LDS: one coalesced copy instead of a
     //      dependent matrix fetch in front of every tree level (measured 0.65 / 1.25 us per level without it)
     const bool sweeping = !(flags & F_NO_SWEEP) && !crown_blk;
     const bool lds_mats = a.lds_mats && sweeping && !(P::REGROWS && a.team_reg);
-    double *lm = x.lds_mats();
+    real *lm = x.lds_mats();
     const int n_sw = (stages - 1) * dm.sw_stride, n_b = p.d() * p.nx() * p.nu();
     if (lds_mats) {
-        const double *src = a.mats + dm.mSweep + (long)root_stage * dm.sw_stride;
-        const double *srcB = a.mats + dm.mB;
+        const real *src = a.mats + dm.mSweep + (long)root_stage * dm.sw_stride;
+        const real *srcB = a.mats + dm.mB;
         x.each([&](int tid, TState<P> &) {
             for (int k = tid; k < n_sw; k += x.nthreads()) lm[k] = src[k];
             for (int k = tid; k < n_b; k += x.nthreads()) lm[n_sw + k] = srcB[k];
@@ -148,7 +148,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     for (int k = 0; k < stages - 1; ++k) ngl_grp *= p.d();
     TeamLds tl;
     tl.XQ = ex; tl.ED = tl.XQ + nl_grp * p.nx(); tl.UL = tl.ED + nl_grp * p.nu(); tl.XL = tl.UL + nl_grp * p.nu();
-    double *lds_after_vectors = tl.XL + ngl_grp * p.nx();
+    real *lds_after_vectors = tl.XL + ngl_grp * p.nx();
     if (a.xl_global) {   // the group-leaf vector in global memory (one slice per workgroup), everything else as before
         lds_after_vectors = tl.XL;
         tl.XL = a.xlbuf + ((long)inst * n_groups + g) * a.xl_stride;
@@ -169,12 +169,12 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     const int st_n2 = (MODE == MODE_CROWN) ? ngl_grp * p.nx() : 0;
     const bool staged = team && (st_n1 + st_n2 > 0) && (st_n1 + st_n2 <= kStageRegs * x.nthreads());
     if (staged) {
-        const double *qg = a.qroot + (long)inst * dm.nsub * dm.nx;
-        const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+        const real *qg = a.qroot + (long)inst * dm.nsub * dm.nx;
+        const real *db = a.dbuf + (long)inst * dm.nn * dm.nu;
         x.each([&](int tid, TState<P> &s) {
             for (int j = 0; j < kStageRegs; ++j) {
                 const int k = tid + j * x.nthreads();
-                double val = 0.;
+                real val = 0.;
                 if (MODE == MODE_CROWN) {
                     if (k < st_n1) val = cb[k];
                     else if (k < st_n1 + st_n2) val = qg[k - st_n1];
@@ -190,7 +190,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         });
     }
 
-    const double gamma = ctl.gamma, sigma = ctl.sigma;
+    const real gamma = ctl.gamma, sigma = ctl.sigma;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nthr = x.nthreads();
     auto level_geo = [&](int l, int &lfirst, int &cnt, long &gfirst) SPK_LAMBDA_INLINE {
         cnt = 1; lfirst = 0;
@@ -200,12 +200,12 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // lane-team node-local phases (large nx / nu, diagonal costs): T lanes per node, team scratch behind the sweep vectors
     const bool team_local = P::TEAMLOCAL;
     const int TT = a.team > 0 ? a.team : 8, nteams = nthr / TT;
-    double *tscr = lds_after_vectors;
+    real *tscr = lds_after_vectors;
     const int tscr_stride = team_scratch_doubles(nu, p.ny() + 2 * d, d, TT);
 
     // ---- phase A (node-local) on the iterate (zi, vi); its part of zbar goes to zout, c_i / e_i (and the leaves' xbar) to
     //      the thread state or the lane teams' LDS vectors, for the crown's extra workgroup to cbuf
-    auto phase_a = [&](const double *zi, const double *vi, double *zout, const double *v2x) SPK_LAMBDA_INLINE {
+    auto phase_a = [&](const real *zi, const real *vi, real *zout, const real *v2x) SPK_LAMBDA_INLINE {
         if (flags & F_NO_ALOCAL) return;
         if (team_local) {
             for (int base = 0; base < nl_grp; base += nteams) {
@@ -221,8 +221,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                         const int tm = tid / TT, r = tid - tm * TT;
                         if (tm >= nteams) return;
                         const TeamNode tn = team_node(dm, d, base + tm, nl_grp, root_stage, root_pos, stages, crown);
-                        double *cq = crown_blk ? cb + tn.li * nx : tl.XQ + tn.li * nx;
-                        double *ce = crown_blk ? cb + nl_grp * nx + tn.li * nu : tl.ED + tn.li * nu;
+                        real *cq = crown_blk ? cb + tn.li * nx : tl.XQ + tn.li * nx;
+                        real *ce = crown_blk ? cb + nl_grp * nx + tn.li * nu : tl.ED + tn.li * nu;
                         ta_p2(p, dm, M, zout, tn, r, TT, tscr + tm * tscr_stride, cq, ce, s.tlr);
                     });
                 x.barrier();
@@ -254,7 +254,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         if (!sweeping || (flags & F_DBG_NO_BWD)) return;
         if (team) {   // lane-team version (all sweep vectors in LDS)
             if (MODE == MODE_CROWN) {   // c_i, e_i of the crown and q of the subtree roots -> LDS
-                const double *qg = a.qroot + (long)inst * dm.nsub * dm.nx;
+                const real *qg = a.qroot + (long)inst * dm.nsub * dm.nx;
                 x.each([&](int tid, TState<P> &s) {
                     if (staged) {   // XQ and ED are adjacent in LDS, exactly like c | e in cbuf
                         for (int j = 0; j < kStageRegs; ++j) {
@@ -281,7 +281,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                         x.each([&](int tid, TState<P> &s) { team_reg_init(p, dm, M, root_stage, stages, team, tid, s, 2); });
                     x.each([&](int, TState<P> &s) { if (s.tn_li >= 0 && s.tn_lvl == l) bwd_team_reg(p, stages, tl, s); });
                 } else if (lds_mats) {
-                    const double *SW = lm + l * dm.sw_stride;
+                    const real *SW = lm + l * dm.sw_stride;
                     x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 } else {
                     const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
@@ -295,8 +295,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 stamp();   // one per backward level
             }
             if (stores_q) {   // q at the subtree root and every d_i -> HBM (level chunks are contiguous)
-                double *q_out = a.qroot + ((long)inst * dm.nsub + g) * dm.nx;
-                double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+                real *q_out = a.qroot + ((long)inst * dm.nsub + g) * dm.nx;
+                real *db = a.dbuf + (long)inst * dm.nn * dm.nu;
                 x.each([&](int tid, TState<P> &) {
                     if (tid < nx) q_out[tid] = tl.XQ[tid];
                     for (int l = 0; l <= stages - 2; ++l) {
@@ -316,11 +316,11 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 for (int k = 0; k < nu; ++k) s.ub[k] = cb[nl_grp * nx + tid * nu + k];
             });
         }
-        const double *qg = (MODE == MODE_CROWN) ? a.qroot + (long)inst * dm.nsub * dm.nx : nullptr;
-        double *q_out = stores_q ? a.qroot + ((long)inst * dm.nsub + g) * dm.nx : nullptr;
+        const real *qg = (MODE == MODE_CROWN) ? a.qroot + (long)inst * dm.nsub * dm.nx : nullptr;
+        real *q_out = stores_q ? a.qroot + ((long)inst * dm.nsub + g) * dm.nx : nullptr;
         for (int l = stages - 2; l >= 0; --l) {
             if (lds_mats) {
-                const double *SW = lm + l * dm.sw_stride;
+                const real *SW = lm + l * dm.sw_stride;
                 x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) bwd_node(p, dm, SW, tid, ex, qg, q_out, s); });
             } else {
                 const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
@@ -330,7 +330,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
             stamp();   // one per backward level
         }
         if (stores_q) {
-            double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+            real *db = a.dbuf + (long)inst * dm.nn * dm.nu;
             x.each([&](int, TState<P> &s) {
                 if (s.active) for (int k = 0; k < nu; ++k) db[s.node * nu + k] = s.dd[k];
             });
@@ -341,10 +341,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     const bool loads_d = (MODE == MODE_SUB_B || MODE == MODE_SUB_BA);
     auto forward = [&]() SPK_LAMBDA_INLINE {
         if (!sweeping || (flags & F_DBG_NO_FWD)) return;
-        const double *xroot = loads_d ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
-        const double *db = a.dbuf + (long)inst * dm.nn * dm.nu;
+        const real *xroot = loads_d ? zo + dm.zx + (long)root_node * dm.nx : a.x0 + (long)inst * dm.nx;
+        const real *db = a.dbuf + (long)inst * dm.nn * dm.nu;
         if (team) {
-            const double *lmB = lm + n_sw;
+            const real *lmB = lm + n_sw;
             const MatPtr gB = M + dm.mB;
             x.each([&](int tid, TState<P> &s) {
                 if (tid < nx) tl.XQ[tid] = xroot[tid];
@@ -366,7 +366,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 if (team_reg) {
                     x.each([&](int, TState<P> &s) { if (s.tn_li >= 0 && s.tn_lvl == l) fwd_team_reg(p, stages, tl, s); });
                 } else if (lds_mats) {
-                    const double *SW = lm + l * dm.sw_stride;
+                    const real *SW = lm + l * dm.sw_stride;
                     x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, lmB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 } else {
                     const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
@@ -406,7 +406,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         }
         for (int l = 0; l <= stages - 2; ++l) {
             if (lds_mats) {
-                const double *SW = lm + l * dm.sw_stride, *Bm = lm + n_sw;
+                const real *SW = lm + l * dm.sw_stride, *Bm = lm + n_sw;
                 x.each([&](int tid, TState<P> &s) { if (s.active && s.lvl == l) fwd_node(p, dm, SW, Bm, tid, ex, xroot, s); });
             } else {
                 const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride, Bm = M + dm.mB;
@@ -437,15 +437,15 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         if (team_local) {
             const bool from_zb = (bflags & F_NO_SWEEP) != 0;
             x.each([&](int, TState<P> &s) { s.mx3[0] = s.mx3[1] = s.mx3[2] = 0.; s.sp3[0] = s.sp3[1] = s.sp3[2] = 0.; });
-            const double *dz_ = (SP_SUMS && a.dir) ? a.dir + (long)inst * a.stride_z : nullptr;
+            const real *dz_ = (SP_SUMS && a.dir) ? a.dir + (long)inst * a.stride_z : nullptr;
             for (int base = 0; base < nl_grp; base += nteams) {
                 x.each([&](int tid, TState<P> &s) {
                     const int tm = tid / TT, r = tid - tm * TT;
                     if (tm >= nteams) return;
                     const TeamNode tn = team_node(dm, d, base + tm, nl_grp, root_stage, root_pos, stages, crown);
-                    const double *xs = from_zb ? zo + dm.zx + (long)tn.node * nx : tl.XQ + tn.li * nx;
-                    const double *us = from_zb ? zo + dm.zu + (long)tn.node * nu : tl.UL + tn.li * nu;
-                    const double *xl = from_zb ? zo + dm.zx + (long)tn.c0 * nx : tl.XL + (tn.pos * d) * nx;
+                    const real *xs = from_zb ? zo + dm.zx + (long)tn.node * nx : tl.XQ + tn.li * nx;
+                    const real *us = from_zb ? zo + dm.zu + (long)tn.node * nu : tl.UL + tn.li * nu;
+                    const real *xl = from_zb ? zo + dm.zx + (long)tn.c0 * nx : tl.XL + (tn.pos * d) * nx;
                     tb_p1(p, dm, M, z, v, zo, tn, r, TT, tscr + tm * tscr_stride, xs, us, xl, nx, ps, bflags, s.tlr);
                 });
                 x.barrier();
@@ -471,7 +471,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
             const bool leaf_shadow = CAN_SHADOW && team_reg && !crown_blk && !(bflags & F_NO_SWEEP) && nl_grp <= 64 && nthr >= 128 &&
                                      (root_stage + stages == dm.N);
             x.each([&](int tid, TState<P> &s) {
-                double mx[3] = {0., 0., 0.};
+                real mx[3] = {0., 0., 0.};
                 if constexpr (CAN_SHADOW) {
                     if (s.active) {
                         if (leaf_shadow) b_local<P, 0, 1>(p, dm, M, z, v, zo, vo, s, ps, bflags, mx);
@@ -489,14 +489,14 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 x.stash3(tid, mx);
             });
         } else {   // SP driver: the inner products with the residual of this evaluation ride along (b_local, SPM)
-            const double *dz_ = a.dir ? a.dir + (long)inst * a.stride_z : nullptr;
+            const real *dz_ = a.dir ? a.dir + (long)inst * a.stride_z : nullptr;
             // Latency regime (register-resident sweep: T threads per node, so phase B keeps one wave busy and leaves the
             // others idle): the residuals of the direction d (below) are formed AT THE SAME TIME by the second wave --
             // thread 64 + li does node li -- instead of after phase B by the first.
             const int shadow0 = 64;
             const bool lop_shadow = a.sp_mode == 2 && nl_grp <= 64 && nthr >= 128;
             x.each([&](int tid, TState<P> &s) {
-                double mx[3] = {0., 0., 0.}, sp[3] = {0., 0., 0.};
+                real mx[3] = {0., 0., 0.}, sp[3] = {0., 0., 0.};
                 s.mx3[0] = s.mx3[1] = s.mx3[2] = 0.;
                 if (s.active) {
                     if (a.sp_mode == 2) b_local<P, 2>(p, dm, M, z, v, zo, vo, s, ps, bflags, mx, sp, dz_, dz_ + dm.nz);
@@ -519,7 +519,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
             x.reduce_sum3();
             x.each([&](int tid, TState<P> &) { if (tid < 3) partials[(long)slot * kPartialStride + 4 + tid] = x.sum3(tid); });
             if (a.sp_mode == 2) {   // the termination residuals of the direction d itself (K1 step: dp = d), spock_sp.hpp: sp_ctl_cd
-                const double *dd_ = a.dir + (long)inst * a.stride_z;
+                const real *dd_ = a.dir + (long)inst * a.stride_z;
                 const bool lop_shadow = !team_local && nl_grp <= 64 && nthr >= 128;   // done next to phase B (above)
                 x.each([&](int tid, TState<P> &s) {
                     double acc[4] = {0., 0., 0., 0.};
@@ -560,8 +560,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         // this workgroup (hence the barrier) or by an earlier launch, with one exception: the crown's workgroup needs
         // vbar.v2 of the subtree roots, which their own workgroups produce in this same launch; it recomputes them.
         x.barrier();
-        double *zn = a.z_next + (long)inst * a.stride_z;
-        double *v2x = crown_blk ? a.v2x + (long)inst * dm.nsub : nullptr;
+        real *zn = a.z_next + (long)inst * a.stride_z;
+        real *v2x = crown_blk ? a.v2x + (long)inst * dm.nsub : nullptr;
         const ProxScal ps = make_ps();
         if (crown_blk)
             x.each([&](int, TState<P> &s) {

@@ -52,7 +52,7 @@ constexpr bool kFuseNextA = false;
 template <class P>
 struct IState {
     TState<P> s;
-    double mx[4];   // xi_1, xi_2, xi maxima and the NaN poison accumulator (spk_resmax)
+    real mx[4];   // xi_1, xi_2, xi maxima and the NaN poison accumulator (spk_resmax)
     bool live;
 };
 
@@ -65,8 +65,8 @@ SPK_DEV int igroup_nonleaf(int d, int stages) {   // non-leaf nodes of a complet
 // X (execution policy): each(f) runs f(tid, IState&) for every thread; barrier(); lds() the q / x exchange slots;
 // live_flags() 64 ints in LDS; red() [waves][3][64] doubles in LDS; nthreads()
 template <class P, int MODE, bool WX, class X>
-SPK_DEV void igroup_body(X &x, const KArgs &a, const double *zin_, const double *vin_, double *zout_, double *vout_,
-                         double *znext_, int tile, int g) {
+SPK_DEV void igroup_body(X &x, const KArgs &a, const real *zin_, const real *vin_, real *zout_, real *vout_,
+                         real *znext_, int tile, int g) {
     const Dims &dm = a.dm;
     const P p(dm);
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu;
@@ -106,11 +106,11 @@ SPK_DEV void igroup_body(X &x, const KArgs &a, const double *zin_, const double 
     x.each([&](int, IState<P> &st) SPK_ILAMBDA { st.mx[0] = st.mx[1] = st.mx[2] = st.mx[3] = 0.; });
 
     // views of this tile's columns: base pointers are wave-uniform, the lane offset is added per thread (vw)
-    const double *zin = zin_ + t64, *vin = vin_ + t64;
-    double *zout = zout_ + t64, *vout = vout_ + t64, *znext = znext_ ? znext_ + t64 : nullptr;
-    double *dbuf = a.dbuf + t64, *cbuf = a.cbuf + t64, *cq = a.cq ? a.cq + t64 : nullptr;
+    const real *zin = zin_ + t64, *vin = vin_ + t64;
+    real *zout = zout_ + t64, *vout = vout_ + t64, *znext = znext_ ? znext_ + t64 : nullptr;
+    real *dbuf = a.dbuf + t64, *cbuf = a.cbuf + t64, *cq = a.cq ? a.cq + t64 : nullptr;
     const long n_cb = (long)igroup_nonleaf(d, dm.t0 + 1);
-    auto vw = [&](const double *b, long n_elems, int tid) SPK_ILAMBDA { return b ? ivec_make(b, bp, tid & 63, n_elems) : ivec_null(); };
+    auto vw = [&](const real *b, long n_elems, int tid) SPK_ILAMBDA { return b ? ivec_make(b, bp, tid & 63, n_elems) : ivec_null(); };
     auto lvw = [&](int tid) SPK_ILAMBDA { return LVec{x.lds() + (tid & 63)}; };
     const long n_db = (long)dm.nn * nu, n_cbuf = n_cb * nxu;
 
@@ -152,12 +152,12 @@ SPK_DEV void igroup_body(X &x, const KArgs &a, const double *zin_, const double 
         x.each([&](int tid, IState<P> &st) SPK_ILAMBDA {
             if (!st.live) return;
             const int wave = spk_uniform(tid >> 6);
-            const double gamma = a.ctl[tile * 64 + (tid & 63)].gamma;
+            const real gamma = a.ctl[tile * 64 + (tid & 63)].gamma;
             const IVec z = vw(zin, dm.nz, tid), v = vw(vin, dm.nv, tid), zo = vw(zout, dm.nz, tid), cb = vw(cbuf, n_cbuf, tid);
             for (int tau = t_lo + wave; tau < t_hi; tau += nW) {
                 TState<P> &s = st.s;
                 init_geometry(p, dm, tau, 0, 0, stages, true, s);
-                a_local_g(p, dm, M, z, v, zo, s, gamma, 0u, (const double *)nullptr);
+                a_local_g(p, dm, M, z, v, zo, s, gamma, 0u, (const real *)nullptr);
                 for (int k = 0; k < nx; ++k) cb[tau * nx + k] = s.xb[k];
                 for (int k = 0; k < nu; ++k) cb[crown_nl * nx + tau * nu + k] = s.ub[k];
             }
@@ -196,12 +196,12 @@ SPK_DEV void igroup_body(X &x, const KArgs &a, const double *zin_, const double 
     auto a_step = [&](int tid, TState<P> &s, const IVec &zi, const IVec &vi, const IVec &zn, const IVec &zprev, const IVec &vprev,
                       const ProxScal &ps, bool recompute_v2) SPK_ILAMBDA {
         if (bottom_grp || !recompute_v2) {
-            a_local_g(p, dm, M, zi, vi, zn, s, ps.gamma, 0u, (const double *)nullptr);
+            a_local_g(p, dm, M, zi, vi, zn, s, ps.gamma, 0u, (const real *)nullptr);
         } else {
             V2Reg<P::MAXD> v2c;
             v2c.base = s.pos * d;
             for (int c = 0; c < d; ++c)
-                v2c.v[c] = s.kids_gleaf ? risk_v2_only(p, dm, M, zprev, vprev, zi, s.c0 + c, ps) : (double)vi[dm.o2 + s.c0 + c];
+                v2c.v[c] = s.kids_gleaf ? risk_v2_only(p, dm, M, zprev, vprev, zi, s.c0 + c, ps) : (real)vi[dm.o2 + s.c0 + c];
             a_local_g(p, dm, M, zi, vi, zn, s, ps.gamma, 0u, v2c);
         }
     };
@@ -246,7 +246,7 @@ SPK_DEV void igroup_body(X &x, const KArgs &a, const double *zin_, const double 
                 const ProxScal ps = make_ps(ctl);
                 const IVec z = vw(zin, dm.nz, tid), v = vw(vin, dm.nv, tid);
                 const IVec zo = vw(zout, dm.nz, tid), vo = vw(vout, dm.nv, tid), zn = vw(znext, dm.nz, tid);
-                const double *x0 = a.x0 + (long)(tile * 64 + (tid & 63)) * nx;
+                const real *x0 = a.x0 + (long)(tile * 64 + (tid & 63)) * nx;
                 for (int pos = wave; pos < cnt; pos += nW) {
                     const int tau = lfirst + pos;
                     TState<P> &s = st.s;
@@ -261,7 +261,7 @@ SPK_DEV void igroup_body(X &x, const KArgs &a, const double *zin_, const double 
                         // gathered from registers (ANext), nothing is read back from memory
                         ANext<P> an;
                         b_local_g<P, 0, 0>(p, dm, M, z, v, zo, vo, s, ps, 0u, st.mx, nullptr, nullptr, nullptr, &an);
-                        double xbar[P::MAXNX], ubar[P::MAXNU];
+                        real xbar[P::MAXNX], ubar[P::MAXNU];
                         for (int k = 0; k < nx; ++k) xbar[k] = -ps.gamma * an.ax[k] + s.xb[k];
                         for (int k = 0; k < nu; ++k) ubar[k] = -ps.gamma * an.au[k] + s.ub[k];
                         for (int c = 0; c < d; ++c)

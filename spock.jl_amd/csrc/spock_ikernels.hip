@@ -11,12 +11,13 @@ namespace spock {
 template <class P>
 struct GpuIExec {
     IState<P> st;
-    double *ex, *rd;
+    real *ex;
+    double *rd;      // residual maxima across the waves: double whatever `real` is
     int *lf;
     template <class F>
     __device__ __forceinline__ void each(F &&f) { f((int)threadIdx.x, st); }
     __device__ __forceinline__ void barrier() { __syncthreads(); }
-    __device__ __forceinline__ double *lds() { return ex; }
+    __device__ __forceinline__ real *lds() { return ex; }
     __device__ __forceinline__ double *red() { return rd; }
     __device__ __forceinline__ int *live_flags() { return lf; }
     __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
@@ -29,11 +30,11 @@ struct GpuIExec {
 #endif
 template <class P, int MODE, bool WX>
 __global__ void __launch_bounds__(256, MODE == MODE_FINALIZE ? 1 : SPOCK_ILV_MIN_WAVES)
-spock_igroup_kernel(const KArgs a, const double *__restrict__ zin, const double *__restrict__ vin, double *__restrict__ zout,
-                    double *__restrict__ vout, double *__restrict__ znext) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+spock_igroup_kernel(const KArgs a, const real *__restrict__ zin, const real *__restrict__ vin, real *__restrict__ zout,
+                    real *__restrict__ vout, real *__restrict__ znext) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // carved in units of 8 bytes (ilv_geometry) whatever `real` is
     GpuIExec<P> x;
-    x.ex = smem;
+    x.ex = reinterpret_cast<real *>(smem);
     x.rd = smem + a.ex_doubles;
     x.lf = reinterpret_cast<int *>(x.rd + (blockDim.x >> 6) * 3 * 64);
     igroup_body<P, MODE, WX>(x, a, zin, vin, zout, vout, znext, (int)blockIdx.y + a.tile0, (int)blockIdx.x);
@@ -49,8 +50,8 @@ static int launch_ivariant(int mode, const KArgs &a_in, hipStream_t st) {
     const size_t lds = g.lds_bytes;
     if (lds > 64 * 1024) return (int)hipErrorInvalidConfiguration;   // ilv_geometry / choose_split_stage_ilv keep it below
     // znext aliases nothing the kernel reads (third z buffer); for SUB_A / CROWN it is unused
-    const double *cn = nullptr;
-    double *dn = nullptr;
+    const real *cn = nullptr;
+    real *dn = nullptr;
     switch (mode) {
         case MODE_SUB_A: hipLaunchKernelGGL((spock_igroup_kernel<P, MODE_SUB_A, false>), grid, block, lds, st, a, a.z_in, a.v_in, a.z_out, a.v_out, dn); break;
         case MODE_ICROWN_A: hipLaunchKernelGGL((spock_igroup_kernel<P, MODE_ICROWN_A, false>), grid, block, lds, st, a, a.z_in, a.v_in, a.z_out, a.v_out, dn); break;
@@ -73,9 +74,9 @@ static int launch_ivariant(int mode, const KArgs &a_in, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) spock_transpose_kernel(double *__restrict__ dst, const double *__restrict__ src, long rows, long cols,
+__global__ void __launch_bounds__(256) spock_transpose_kernel(real *__restrict__ dst, const real *__restrict__ src, long rows, long cols,
                                                               long ld_src, long ld_dst) {
-    __shared__ double tile[32][33];
+    __shared__ real tile[32][33];
     const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int k = ty; k < 32; k += 8) {
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(256) spock_transpose_kernel(double *__restrict
     }
 }
 
-int launch_transpose(double *dst, const double *src, long rows, long cols, long ld_src, long ld_dst, void *stream) {
+int launch_transpose(real *dst, const real *src, long rows, long cols, long ld_src, long ld_dst, void *stream) {
     if (rows <= 0 || cols <= 0) return 0;
     const dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
     hipLaunchKernelGGL(spock_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, dst, src, rows, cols, ld_src, ld_dst);
@@ -97,19 +98,19 @@ int launch_transpose(double *dst, const double *src, long rows, long cols, long 
 }
 
 // after a solve: the final iterate of instance b sits in the buffers its control block's result_parity names; bring it to slot 0
-__global__ void __launch_bounds__(256) spock_ilv_collect_kernel(double *z0, const double *z1, const double *z2, double *v0, const double *v1,
+__global__ void __launch_bounds__(256) spock_ilv_collect_kernel(real *z0, const real *z1, const real *z2, real *v0, const real *v1,
                                                                 const Ctl *ctl, long nz, long nv, long bp, int batch) {
     const long b = (long)blockIdx.x * 64 + (threadIdx.x & 63);
     if (b >= batch) return;
     const int rp = ctl[b].result_parity;
-    const double *zs = (rp % 3 == 1) ? z1 : ((rp % 3 == 2) ? z2 : nullptr);
-    const double *vs = (rp % 2) ? v1 : nullptr;
+    const real *zs = (rp % 3 == 1) ? z1 : ((rp % 3 == 2) ? z2 : nullptr);
+    const real *vs = (rp % 2) ? v1 : nullptr;
     const int sub = threadIdx.x >> 6;   // 4 element rows per pass
     if (zs) for (long e = (long)blockIdx.y * 4 + sub; e < nz; e += (long)gridDim.y * 4) z0[e * bp + b] = zs[e * bp + b];
     if (vs) for (long e = (long)blockIdx.y * 4 + sub; e < nv; e += (long)gridDim.y * 4) v0[e * bp + b] = vs[e * bp + b];
 }
 
-int launch_ilv_collect(double *const *z3, double *const *v2, const Ctl *ctl, long nz, long nv, long bp, int batch, void *stream) {
+int launch_ilv_collect(real *const *z3, real *const *v2, const Ctl *ctl, long nz, long nv, long bp, int batch, void *stream) {
     const dim3 grid((unsigned)(bp / 64), 256);
     hipLaunchKernelGGL(spock_ilv_collect_kernel, grid, dim3(256), 0, (hipStream_t)stream, z3[0], z3[1], z3[2], v2[0], v2[1], ctl, nz, nv, bp, batch);
     return (int)hipGetLastError();

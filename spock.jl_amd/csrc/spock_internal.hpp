@@ -6,6 +6,16 @@
 
 namespace spock {
 
+// Arithmetic / storage type of the device path.  The product library (libspock_amd.so) is built with double -- "Float64 is baked
+// in" in the reference (src/model.jl:304-307).  libspock_amd_f32.so is the same source built with -DSPOCK_REAL=float (and
+// single-precision literals): the fp32 variant of BASELINE config 5's tolerance study.  The C ABI is double either way; the
+// control blocks, residuals, partial reductions and the host build step stay double.
+#ifndef SPOCK_REAL
+#define SPOCK_REAL double
+#endif
+typedef SPOCK_REAL real;
+constexpr bool kRealIsDouble = sizeof(real) == 8;
+
 constexpr int kMaxStages = 24;
 constexpr int kMaxCones = 8;
 // bounds of the run-time-dimension kernel variant (compile-time variants exist for the benchmark shapes)
@@ -82,20 +92,20 @@ enum KFlags : unsigned {
 
 struct KArgs {
     Dims dm;
-    const double *mats;
-    const double *z_in, *v_in;  // input iterate; instance b starts at z_in + b*stride_z, v_in + b*stride_v
-    double *z_out, *v_out;      // zbar, vbar (same strides)
-    double *z_next;             // SUB_BA only: where phase A of the NEXT iteration puts its part of the next zbar (third z buffer)
-    const double *dir;          // SP, sp_mode 2: the direction d (z | v concatenated per instance like z_in), for <r, P d>
+    const real *mats;
+    const real *z_in, *v_in;  // input iterate; instance b starts at z_in + b*stride_z, v_in + b*stride_v
+    real *z_out, *v_out;      // zbar, vbar (same strides)
+    real *z_next;             // SUB_BA only: where phase A of the NEXT iteration puts its part of the next zbar (third z buffer)
+    const real *dir;          // SP, sp_mode 2: the direction d (z | v concatenated per instance like z_in), for <r, P d>
     int sp_mode;                // SP: 0 none, 1 accumulate <r, P r>, 2 also <r, P d>  (spock_device.hpp: b_local SPM)
-    double *v2x;                // SUB_BA only: [batch][nsub] vbar.v2 of the subtree roots as recomputed by the crown's workgroup
+    real *v2x;                // SUB_BA only: [batch][nsub] vbar.v2 of the subtree roots as recomputed by the crown's workgroup
     long stride_z, stride_v;    // CP: nz, nv (separate arrays); SP: nz + nv for both (z|v concatenated per instance)
-    double *dbuf;               // [batch][nn*nu]      S1's d_i between phase A and phase B
-    double *qroot;              // [batch][nsub*nx]    S1's q at the subtree roots
-    double *cbuf;               // [batch][crown non-leaf nodes][nx+nu]  node-local terms of the crown's sweep
+    real *dbuf;               // [batch][nn*nu]      S1's d_i between phase A and phase B
+    real *qroot;              // [batch][nsub*nx]    S1's q at the subtree roots
+    real *cbuf;               // [batch][crown non-leaf nodes][nx+nu]  node-local terms of the crown's sweep
     double *partials;           // [batch][(nsub+1)*kPartialStride]
     Ctl *ctl;                   // [batch]
-    const double *x0;           // [batch][nx]
+    const real *x0;           // [batch][nx]
     double *hist;               // [batch][hist_cap*kHistStride]
     unsigned long long *dbg;    // [3 kernels][64 stamps][2]: (s_memtime, s_memrealtime) pairs, diagnostic builds of the timing only
     int hist_cap;
@@ -106,13 +116,13 @@ struct KArgs {
     int ex_doubles;             // size of the LDS exchange region (thread path: threads*nx; team path: TeamLds vectors)
     int team_reg;               // lane-team sweep with the matrix rows in registers (small compile-time shapes)
     int team;                   // > 0: lane-team sweeps with this many lanes per node (all sweep vectors in LDS)
-    double *xlbuf;              // [batch][groups][xl_stride]: the group-leaf sweep vector when it does not fit in LDS
+    real *xlbuf;              // [batch][groups][xl_stride]: the group-leaf sweep vector when it does not fit in LDS
     int xl_global, xl_stride;
     // element-major ("interleaved") batched regime (spock_igroup.hpp): every per-instance array is [element][bp], bp = batch
     // rounded up to a multiple of 64; one wave = one tree node x one tile of 64 instances
     int ilv;
     long bp;
-    double *cq;                 // [crown non-leaf nodes][nx][bp]: q / x exchange of the crown's sweep (global memory)
+    real *cq;                 // [crown non-leaf nodes][nx][bp]: q / x exchange of the crown's sweep (global memory)
     int cchunk, n_cchunks;      // crown nodes per workgroup of the node-local crown phases, number of such workgroups
     int want_xi;                // element-major regime: LOG-mode CP (combined residual xi, cp.jl:83-86) selects the kernel variant
     int grp_level;              // element-major regime, I_UP / I_DOWN: the layer of mid groups this launch works on
@@ -135,12 +145,12 @@ constexpr int kSpSums = 10;   // partial sums per workgroup of the flat / LOP ke
 
 struct SpArgs {
     Dims dm;
-    const double *mats;
+    const real *mats;
     Ctl *ctl;
     SpCtl *sp;
     // every vector is [batch][nr], nr = nz + nv, z part first
-    double *Z, *ZB, *ZOLD, *R, *ROLD, *DP, *W, *WB, *RW, *D;
-    double *MP, *Q;            // [batch][3][nr], circular columns
+    real *Z, *ZB, *ZOLD, *R, *ROLD, *DP, *W, *WB, *RW, *D;
+    real *MP, *Q;            // [batch][3][nr], circular columns
     double *partF;             // [batch][n_partF][kSpSums] partial sums of the flat kernels
     double *partL;             // [batch][n_partL][kSpSums] partial sums (0,1) and maxima (2,3) of the LOP kernels
     double *hist;
@@ -207,19 +217,19 @@ bool have_static_variant(int nx, int nu, int d, int ny);
 // closed-loop step of examples/server_heat/mpc_simulation.jl:164-177 on the device
 struct MpcArgs {
     Dims dm;
-    const double *mats;
-    const double *z;        // element e of instance b at z[b * stride_z + e * stride_e] (the u block of node 0 is the applied input)
+    const real *mats;
+    const real *z;        // element e of instance b at z[b * stride_z + e * stride_e] (the u block of node 0 is the applied input)
     long stride_z, stride_e;
-    double *x0;             // [batch][nx], updated in place: x0 <- A_w x0 + B_w u
+    real *x0;             // [batch][nx], updated in place: x0 <- A_w x0 + B_w u
     const int *w_seq;       // [batch][steps] events
-    double *x_traj, *u_traj;  // [batch][steps+1][nx], [batch][steps][nu]
+    real *x_traj, *u_traj;  // [batch][steps+1][nx], [batch][steps][nu]
     int t, steps, batch;
 };
 int launch_mpc_advance(const MpcArgs &a, void *stream);
 // dst[c * ld_dst + r] = src[r * ld_src + c] for r < rows, c < cols (instance-major <-> element-major copies of the state)
-int launch_transpose(double *dst, const double *src, long rows, long cols, long ld_src, long ld_dst, void *stream);
+int launch_transpose(real *dst, const real *src, long rows, long cols, long ld_src, long ld_dst, void *stream);
 // element-major state: column b of z0 / v0 <- column b of the buffer its control block's result_parity names
-int launch_ilv_collect(double *const *z3, double *const *v2, const Ctl *ctl, long nz, long nv, long bp, int batch, void *stream);
+int launch_ilv_collect(real *const *z3, real *const *v2, const Ctl *ctl, long nz, long nv, long bp, int batch, void *stream);
 int launch_sp(const SpArgs &a, void *stream);   // a.op selects the kernel (spock_sp.hpp)
 int sp_flat_blocks(long nr);                    // workgroups per instance of the flat kernels
 int sp_lop_blocks(const Dims &dm);              // workgroups per instance of the LOP kernels

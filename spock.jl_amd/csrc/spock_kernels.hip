@@ -17,17 +17,18 @@ namespace spock {
 template <class P>
 struct GpuExec {
     TState<P> st;
-    double m[3];
-    double *ex, *lm;
+    double m[3];          // residual maxima: reduced in double whatever `real` is
+    real *ex, *lm;
     unsigned long long *red, *stamps;
     int *fl;
     template <class F>
     __device__ __forceinline__ void each(F &&f) { f((int)threadIdx.x, st); }
     __device__ __forceinline__ void barrier() { __syncthreads(); }
-    __device__ __forceinline__ double *lds() { return ex; }
-    __device__ __forceinline__ double *lds_mats() { return lm; }
+    __device__ __forceinline__ real *lds() { return ex; }
+    __device__ __forceinline__ real *lds_mats() { return lm; }
     __device__ __forceinline__ int &flag() { return *fl; }
-    __device__ __forceinline__ void stash3(int, const double *mx) { m[0] = mx[0]; m[1] = mx[1]; m[2] = mx[2]; }
+    template <class T>
+    __device__ __forceinline__ void stash3(int, const T *mx) { m[0] = (double)mx[0]; m[1] = (double)mx[1]; m[2] = (double)mx[2]; }
     __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
     __device__ __forceinline__ unsigned long long *stamp_lds() { return stamps; }
     __device__ __forceinline__ void clocks(unsigned long long *d) { d[0] = __builtin_readcyclecounter(); d[1] = __builtin_amdgcn_s_memrealtime(); }
@@ -49,11 +50,12 @@ struct GpuExec {
         }
         __syncthreads();
     }
-    __device__ __forceinline__ double red3(int k) const { return __longlong_as_double((long long)red[k]); }
+    __device__ __forceinline__ real red3(int k) const { return __longlong_as_double((long long)red[k]); }
     // deterministic sums over the workgroup (SP inner products): fixed shuffle tree per wave, then the waves in order
     double sm[3];
     double *sums;   // LDS [3][16 waves] + [3] results
-    __device__ __forceinline__ void stash_sum3(int, const double *v) { sm[0] = v[0]; sm[1] = v[1]; sm[2] = v[2]; }
+    template <class T>
+    __device__ __forceinline__ void stash_sum3(int, const T *v) { sm[0] = (double)v[0]; sm[1] = (double)v[1]; sm[2] = (double)v[2]; }
     __device__ __forceinline__ void reduce_sum3() {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
 #pragma unroll
@@ -82,14 +84,14 @@ struct GpuExec {
 
 template <class P, int MODE>
 __global__ void __launch_bounds__(P::TEAMLOCAL ? 1024 : 512) SPK_KERNEL_ATTR spock_group_kernel(const KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // carved in units of 8 bytes (launch_geometry) whatever `real` is
     GpuExec<P> x;
-    x.ex = smem;
+    x.ex = reinterpret_cast<real *>(smem);
     x.red = reinterpret_cast<unsigned long long *>(smem + a.ex_doubles);
     x.fl = reinterpret_cast<int *>(x.red + 3);
     x.stamps = reinterpret_cast<unsigned long long *>(smem + a.ex_doubles + 4);
-    x.sums = smem + a.ex_doubles + 4 + 128;
-    x.lm = smem + a.ex_doubles + 4 + 128 + 64;
+    x.sums = reinterpret_cast<double *>(smem + a.ex_doubles + 4 + 128);
+    x.lm = reinterpret_cast<real *>(smem + a.ex_doubles + 4 + 128 + 64);
     const bool wave_stamps = (a.flags & F_DBG_STAMPS) && a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && MODE != MODE_FINALIZE;
     unsigned long long *wd = a.dbg ? a.dbg + (long)(MODE == MODE_SUB_A ? 0 : (MODE == MODE_CROWN ? 1 : 2)) * 128 : nullptr;
     if (wave_stamps) wd[2 * (40 + (threadIdx.x >> 6)) + 1] = __builtin_amdgcn_s_memrealtime();
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(512) spock_sp_lop_kernel(const SpArgs a) {
     init_geometry(p, dm, (int)threadIdx.x, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0,
                   crown ? dm.t0 + 1 : (split ? dm.sub_stages : dm.N), crown, s);
     const long o = (long)inst * a.nr;
-    const double *A = nullptr, *B = nullptr, *B2 = nullptr;
+    const real *A = nullptr, *B = nullptr, *B2 = nullptr;
     if (a.op == SP_LOP_R) { A = a.R + o; B = a.R + o; }
     else if (a.op == SP_LOP_RT) { A = a.RW + o; B = a.RW + o; B2 = a.D + o; }
     else { B = a.DP + o; }
@@ -343,10 +345,10 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
 __global__ void __launch_bounds__(64) spock_mpc_advance_kernel(const MpcArgs a) {
     const int inst = blockIdx.x, r = threadIdx.x;
     const Dims &dm = a.dm;
-    const double *z = a.z + (long)inst * a.stride_z;
-    double *x0 = a.x0 + (long)inst * dm.nx;
+    const real *z = a.z + (long)inst * a.stride_z;
+    real *x0 = a.x0 + (long)inst * dm.nx;
     const int w = a.w_seq[(long)inst * a.steps + a.t];
-    double xn = 0.;
+    real xn = 0.;
     if (r < dm.nx) {
         if (a.t == 0) a.x_traj[((long)inst * (a.steps + 1)) * dm.nx + r] = x0[r];
         xn = mpc_advance_row(dm, (MatPtr)a.mats, z, a.stride_e, x0, w, r);

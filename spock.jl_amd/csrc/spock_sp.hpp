@@ -36,32 +36,32 @@ SPK_DEV int sp_col(const SpCtl &c, int logical /*0 = newest*/) { return (c.head 
 SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, double *sums) {
     const long o = (long)inst * a.nr + e;
     const long m3 = (long)inst * 3 * a.nr;
-    double *q1 = a.Q + m3 + (long)sp_col(c, 0) * a.nr, *q2 = a.Q + m3 + (long)sp_col(c, 1) * a.nr,
+    real *q1 = a.Q + m3 + (long)sp_col(c, 0) * a.nr, *q2 = a.Q + m3 + (long)sp_col(c, 1) * a.nr,
            *q3 = a.Q + m3 + (long)sp_col(c, 2) * a.nr;
-    double *p1 = a.MP + m3 + (long)sp_col(c, 0) * a.nr, *p2 = a.MP + m3 + (long)sp_col(c, 1) * a.nr,
+    real *p1 = a.MP + m3 + (long)sp_col(c, 0) * a.nr, *p2 = a.MP + m3 + (long)sp_col(c, 1) * a.nr,
            *p3 = a.MP + m3 + (long)sp_col(c, 2) * a.nr;
     switch (a.op) {
         case SP_FLAT1: {   // head already points at the slot of the new column (set by CTL_D / solve start)
-            const double z = a.Z[o], r = z - a.ZB[o];
-            const double dr = r - a.ROLD[o];
+            const real z = a.Z[o], r = z - a.ZB[o];
+            const real dr = r - a.ROLD[o];
             a.R[o] = r;
             p1[e] = a.DP[o] - dr;                 // MP[:,1] = delta_p - delta_r   (anderson.jl:25-32)
             q1[e] = dr;                           // Q[:,1]  = MR[:,1] = delta_r   (anderson.jl:63-65)
             a.ROLD[o] = r;                        // update_sy! (sp.jl:232-255)
             a.ZOLD[o] = z;
-            const double b = q2[e], cc = q3[e];
+            const real b = q2[e], cc = q3[e];
             sums[0] += dr * dr; sums[1] += b * dr; sums[2] += cc * dr; sums[3] += b * b; sums[4] += cc * cc; sums[5] += b * cc;
         } break;
         case SP_FLAT2: {
-            const double v = q1[e] - c.r2 * q2[e] - c.r3 * q3[e];   // anderson.jl:88
+            const real v = q1[e] - c.r2 * q2[e] - c.r3 * q3[e];   // anderson.jl:88
             q1[e] = v;
-            const double r = a.R[o];
+            const real r = a.R[o];
             sums[0] += v * v; sums[1] += v * r; sums[2] += q2[e] * r; sums[3] += q3[e] * r;
         } break;
         case SP_FLAT3: {
             q1[e] = q1[e] / c.rho;                                   // anderson.jl:94-98
-            const double w = (p1[e] * c.g[0] + p2[e] * c.g[1]) + p3[e] * c.g[2];   // MP gamma (anderson.jl:116)
-            const double d = -a.R[o] - w;                            // anderson.jl:117-122
+            const real w = (p1[e] * c.g[0] + p2[e] * c.g[1]) + p3[e] * c.g[2];   // MP gamma (anderson.jl:116)
+            const real d = -a.R[o] - w;                            // anderson.jl:117-122
             a.D[o] = d;
             a.W[o] = a.Z[o] + 1. * d;                                // tau = 1 (sp.jl:118-131)
         } break;
@@ -69,7 +69,7 @@ SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, dou
             a.RW[o] = a.W[o] - a.WB[o];                              // sp.jl:155-160
             break;
         case SP_FLAT5: {
-            double z = a.Z[o];
+            real z = a.Z[o];
             if (c.accept == 1) z = a.W[o];                           // K1 (sp.jl:166-191)
             else if (c.accept == 2) z -= c.coef * (a.fused_lop ? a.W[o] - a.WB[o] : a.RW[o]);   // K2 (sp.jl:193-222); rt = w - wbar (:155-160)
             else z = a.ZB[o];                                        // plain CP step (sp.jl:443-446)
@@ -85,30 +85,30 @@ SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, dou
 //   acc[0] += <a, P b>   acc[1] += <a, P b2>      P = [[I, -gamma L'], [-sigma L, I]]   (implicit_l.jl:485-516)
 //   acc[2] = max |L' b_v - b_z / gamma|           acc[3] = max |L b_z - b_v / sigma|    (sp.jl:283-293)
 template <class P>
-SPK_DEV void lop_local(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ A, const double *__restrict__ Bv,
-                       const double *__restrict__ B2, const TState<P> &s, double gamma, double sigma, double *acc) {
+SPK_DEV void lop_local(const P &p, const Dims &dm, MatPtr M, const real *__restrict__ A, const real *__restrict__ Bv,
+                       const real *__restrict__ B2, const TState<P> &s, real gamma, real sigma, double *acc) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
     const int i = s.node, nxu = nx + nu, nz = dm.nz;
-    const double nig = -1. / gamma, nis = -1. / sigma;
+    const real nig = -1. / gamma, nis = -1. / sigma;
     const int nb = B2 ? 2 : 1;
     for (int which = 0; which < nb; ++which) {
-        const double *__restrict__ b = which ? B2 : Bv;
-        const double *bz = b, *bv = b + nz;
-        const double *az = A, *av = A ? A + nz : nullptr;
-        double sum = 0., m1 = acc[2], m2 = acc[3];
+        const real *__restrict__ b = which ? B2 : Bv;
+        const real *bz = b, *bv = b + nz;
+        const real *az = A, *av = A ? A + nz : nullptr;
+        real sum = 0., m1 = acc[2], m2 = acc[3];
         const MatPtr bb = M + dm.mb + (dm.nRm > 1 ? i * ny : 0);
         // ---- z entries x_i, u_i and v entries v7, v3_c, v4_c
-        double bx[P::MAXNX], bu[P::MAXNU], ltx[P::MAXNX], ltu[P::MAXNU];
+        real bx[P::MAXNX], bu[P::MAXNU], ltx[P::MAXNX], ltu[P::MAXNU];
         SPK_UNROLL for (int k = 0; k < nx; ++k) { bx[k] = bz[dm.zx + i * nx + k]; ltx[k] = bv[dm.o7 + i * nxu + k]; }
         SPK_UNROLL for (int k = 0; k < nu; ++k) { bu[k] = bz[dm.zu + i * nu + k]; ltu[k] = bv[dm.o7 + i * nxu + nx + k]; }
         // v7 = (x_i, u_i)
         SPK_UNROLL for (int k = 0; k < nx; ++k) {
-            const double lb = bx[k], vb = ltx[k];
+            const real lb = bx[k], vb = ltx[k];
             if (A) sum += av[dm.o7 + i * nxu + k] * (vb - sigma * lb);
             m2 = spk_max_nan(m2, fabs(lb + nis * vb));
         }
         SPK_UNROLL for (int k = 0; k < nu; ++k) {
-            const double lb = bu[k], vb = ltu[k];
+            const real lb = bu[k], vb = ltu[k];
             if (A) sum += av[dm.o7 + i * nxu + nx + k] * (vb - sigma * lb);
             m2 = spk_max_nan(m2, fabs(lb + nis * vb));
         }
@@ -116,24 +116,24 @@ SPK_DEV void lop_local(const P &p, const Dims &dm, MatPtr M, const double *__res
             const int j = s.c0 + c, jn = j - 1;
             const MatPtr SQ = M + dm.mSqQ + (P::SHARED ? 0 : jn) * nx * nx;
             const MatPtr SR = M + dm.mSqR + (P::SHARED ? 0 : jn) * nu * nu;
-            double l3[P::MAXNX], l4[P::MAXNU];
+            real l3[P::MAXNX], l4[P::MAXNU];
             sym_mv<P, false>(nx, SQ, bx, l3);                 // (L b_z) on v3_j
             sym_mv<P, false>(nu, SR, bu, l4);                 // (L b_z) on v4_j
             sym_mv<P, true>(nx, SQ, bv + dm.o3 + jn * nx, ltx);   // L' contribution to x_i
             sym_mv<P, true>(nu, SR, bv + dm.o4 + jn * nu, ltu);   // L' contribution to u_i
             SPK_UNROLL for (int k = 0; k < nx; ++k) {
-                const double vb = bv[dm.o3 + jn * nx + k];
+                const real vb = bv[dm.o3 + jn * nx + k];
                 if (A) sum += av[dm.o3 + jn * nx + k] * (vb - sigma * l3[k]);
                 m2 = spk_max_nan(m2, fabs(l3[k] + nis * vb));
             }
             SPK_UNROLL for (int k = 0; k < nu; ++k) {
-                const double vb = bv[dm.o4 + jn * nu + k];
+                const real vb = bv[dm.o4 + jn * nu + k];
                 if (A) sum += av[dm.o4 + jn * nu + k] * (vb - sigma * l4[k]);
                 m2 = spk_max_nan(m2, fabs(l4[k] + nis * vb));
             }
             // tau_j <-> v5_j, v6_j
-            const double bt = bz[dm.zt + jn], b5 = bv[dm.o5 + jn], b6 = bv[dm.o6 + jn];
-            const double lt = 0.5 * b5 + 0.5 * b6, l56 = 0.5 * bt;
+            const real bt = bz[dm.zt + jn], b5 = bv[dm.o5 + jn], b6 = bv[dm.o6 + jn];
+            const real lt = 0.5 * b5 + 0.5 * b6, l56 = 0.5 * bt;
             if (A) sum += az[dm.zt + jn] * (bt - gamma * lt) + av[dm.o5 + jn] * (b5 - sigma * l56) + av[dm.o6 + jn] * (b6 - sigma * l56);
             m1 = spk_max_nan(m1, fabs(lt + nig * bt));
             m2 = spk_max_nan(m2, fabs(l56 + nis * b5));
@@ -141,21 +141,21 @@ SPK_DEV void lop_local(const P &p, const Dims &dm, MatPtr M, const double *__res
             if (s.kids_leaf) {
                 const int li = j - dm.nn;
                 const MatPtr SN = M + dm.mSqQN + (P::SHARED ? 0 : li) * nx * nx;
-                double bxl[P::MAXNX], l11[P::MAXNX], lt11[P::MAXNX];
+                real bxl[P::MAXNX], l11[P::MAXNX], lt11[P::MAXNX];
                 SPK_UNROLL for (int k = 0; k < nx; ++k) bxl[k] = bz[dm.zx + j * nx + k];
                 sym_mv<P, false>(nx, SN, bxl, l11);
                 sym_mv<P, false>(nx, SN, bv + dm.o11 + li * nx, lt11);
                 SPK_UNROLL for (int k = 0; k < nx; ++k) {
-                    const double v11 = bv[dm.o11 + li * nx + k], v14 = bv[dm.o14 + li * nx + k];
-                    const double ltxl = v14 + lt11[k];
+                    const real v11 = bv[dm.o11 + li * nx + k], v14 = bv[dm.o14 + li * nx + k];
+                    const real ltxl = v14 + lt11[k];
                     if (A) sum += az[dm.zx + j * nx + k] * (bxl[k] - gamma * ltxl) + av[dm.o11 + li * nx + k] * (v11 - sigma * l11[k])
                                   + av[dm.o14 + li * nx + k] * (v14 - sigma * bxl[k]);
                     m1 = spk_max_nan(m1, fabs(ltxl + nig * bxl[k]));
                     m2 = spk_max_nan(m2, fabs(l11[k] + nis * v11));
                     m2 = spk_max_nan(m2, fabs(bxl[k] + nis * v14));
                 }
-                const double bs = bz[dm.zs + j], b12 = bv[dm.o12 + li], b13 = bv[dm.o13 + li];
-                const double lts = 0.5 * b12 + 0.5 * b13, l1213 = 0.5 * bs;
+                const real bs = bz[dm.zs + j], b12 = bv[dm.o12 + li], b13 = bv[dm.o13 + li];
+                const real lts = 0.5 * b12 + 0.5 * b13, l1213 = 0.5 * bs;
                 if (A) sum += az[dm.zs + j] * (bs - gamma * lts) + av[dm.o12 + li] * (b12 - sigma * l1213) + av[dm.o13 + li] * (b13 - sigma * l1213);
                 m1 = spk_max_nan(m1, fabs(lts + nig * bs));
                 m2 = spk_max_nan(m2, fabs(l1213 + nis * b12));
@@ -171,17 +171,17 @@ SPK_DEV void lop_local(const P &p, const Dims &dm, MatPtr M, const double *__res
             m1 = spk_max_nan(m1, fabs(ltu[k] + nig * bu[k]));
         }
         // ---- y_i, s_i <-> v1_i, v2_i
-        const double bs = bz[dm.zs + i], b2v = bv[dm.o2 + i];
-        double bdot = 0.;
+        const real bs = bz[dm.zs + i], b2v = bv[dm.o2 + i];
+        real bdot = 0.;
         SPK_UNROLL for (int k = 0; k < ny; ++k) {
-            const double by = bz[dm.zy + i * ny + k], b1 = bv[i * ny + k];
+            const real by = bz[dm.zy + i * ny + k], b1 = bv[i * ny + k];
             bdot += bb[k] * by;
-            const double lty = b1 - bb[k] * b2v;                     // (L' b_v) on y
+            const real lty = b1 - bb[k] * b2v;                     // (L' b_v) on y
             if (A) sum += az[dm.zy + i * ny + k] * (by - gamma * lty) + av[i * ny + k] * (b1 - sigma * by);
             m1 = spk_max_nan(m1, fabs(lty + nig * by));
             m2 = spk_max_nan(m2, fabs(by + nis * b1));
         }
-        const double l2 = bs - bdot;                                  // (L b_z) on v2
+        const real l2 = bs - bdot;                                  // (L b_z) on v2
         if (A) sum += az[dm.zs + i] * (bs - gamma * b2v) + av[dm.o2 + i] * (b2v - sigma * l2);
         m1 = spk_max_nan(m1, fabs(b2v + nig * bs));
         m2 = spk_max_nan(m2, fabs(l2 + nis * b2v));

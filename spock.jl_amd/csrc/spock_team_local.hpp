@@ -43,41 +43,41 @@ SPK_DEV int team_scratch_doubles(int nu, int m, int d, int T) { return m + nu + 
 // ---------------------------------------------------------------------------------------------------
 // phase A, part 1: zbar0 = (-gamma) L'v + z on the lane's elements; publish [y; s_ch; tau_ch] and ubar
 template <class P>
-SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z, const double *__restrict__ v,
-                   double *__restrict__ zo, const TeamNode &t, int r, int T, double *S, double *XL, double gamma, unsigned flags,
-                   TLReg<P> &g, const double *v2x = nullptr) {
+SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const real *__restrict__ z, const real *__restrict__ v,
+                   real *__restrict__ zo, const TeamNode &t, int r, int T, real *S, real *XL, real gamma, unsigned flags,
+                   TLReg<P> &g, const real *v2x = nullptr) {
     if (!t.active) return;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), nxu = nx + nu, m = ny + 2 * d;
     const int i = t.node;
-    const double mg = -gamma;
+    const real mg = -gamma;
     const bool raw = (flags & F_RAW_LT) != 0;
     const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb + (dm.nRm > 1 ? t.node * p.ny() : 0);
-    double *vec = S, *ubs = S + m;
+    real *vec = S, *ubs = S + m;
     if (r < nx) {   // x_i[r] <- v7 + sum_j sqrtQ v3_j  (implicit_l.jl:351-373), diagonal sqrtQ
-        double acc = v[dm.o7 + i * nxu + r];
+        real acc = v[dm.o7 + i * nxu + r];
         SPK_UNROLL for (int c = 0; c < d; ++c) acc += SQ[r + r * nx] * v[dm.o3 + (t.c0 + c - 1) * nx + r];
         g.xb = mg * acc + z[dm.zx + i * nx + r];
         if (raw) zo[dm.zx + i * nx + r] = g.xb;
         if (t.kids_leaf)   // leaves: x_j <- v14 + sqrtQN v11 (implicit_l.jl:376-396); q_leaf = -xbar_leaf goes to the sweep
             SPK_UNROLL for (int c = 0; c < d; ++c) {
                 const int j = t.c0 + c, li = j - dm.nn;
-                const double xl = mg * (v[dm.o14 + li * nx + r] + SN[r + r * nx] * v[dm.o11 + li * nx + r]) + z[dm.zx + j * nx + r];
+                const real xl = mg * (v[dm.o14 + li * nx + r] + SN[r + r * nx] * v[dm.o11 + li * nx + r]) + z[dm.zx + j * nx + r];
                 if (raw) zo[dm.zx + j * nx + r] = xl;
                 else if (XL) XL[(t.pos * d + c) * nx + r] = -xl;
             }
     }
     if (r < nu) {   // u_i[r] (implicit_l.jl:399-420)
-        double acc = v[dm.o7 + i * nxu + nx + r];
+        real acc = v[dm.o7 + i * nxu + nx + r];
         SPK_UNROLL for (int c = 0; c < d; ++c) acc += SR[r + r * nu] * v[dm.o4 + (t.c0 + c - 1) * nu + r];
         g.ub = mg * acc + z[dm.zu + i * nu + r];
         if (raw) zo[dm.zu + i * nu + r] = g.ub; else ubs[r] = g.ub;
     }
     for (int e = r; e < m; e += T) {   // [y_i ; s_children ; tau_children]  (implicit_l.jl:423-448)
-        double val;
+        real val;
         if (e < ny) val = mg * (v[i * ny + e] - bb[e] * v[dm.o2 + i]) + z[dm.zy + i * ny + e];
         else if (e < ny + d) {
             const int j = t.c0 + (e - ny);
-            const double ls = (v2x && t.kids_gleaf) ? v2x[t.pos * d + (e - ny)]   // crown workgroup of the fused B+A kernel
+            const real ls = (v2x && t.kids_gleaf) ? v2x[t.pos * d + (e - ny)]   // crown workgroup of the fused B+A kernel
                               : (j < dm.nn) ? v[dm.o2 + j] : 0.5 * v[dm.o12 + (j - dm.nn)] + 0.5 * v[dm.o13 + (j - dm.nn)];
             val = mg * ls + z[dm.zs + j];
         } else {
@@ -95,15 +95,15 @@ SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
 
 // phase A, part 2: S2 projector rows, c_i = U ubar - xbar, e_i = Rt^-1 ubar
 template <class P>
-SPK_DEV void ta_p2(const P &p, const Dims &dm, MatPtr M, double *__restrict__ zo, const TeamNode &t, int r, int T,
-                   const double *S, double *cq, double *ce, const TLReg<P> &g) {
+SPK_DEV void ta_p2(const P &p, const Dims &dm, MatPtr M, real *__restrict__ zo, const TeamNode &t, int r, int T,
+                   const real *S, real *cq, real *ce, const TLReg<P> &g) {
     if (!t.active) return;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), m = ny + 2 * d;
     const int i = t.node;
-    const double *vec = S, *ubs = S + m;
+    const real *vec = S, *ubs = S + m;
     const MatPtr LS = M + dm.mLs + (dm.nRm > 1 ? i * m * m : 0);
     for (int e = r; e < m; e += T) {   // implicit_l.jl:708-726
-        double a = 0.;
+        real a = 0.;
         for (int k = 0; k < m; ++k) a += LS[e + k * m] * vec[k];
         if (e < ny) zo[dm.zy + i * ny + e] = a;
         else if (e < ny + d) zo[dm.zs + t.c0 + (e - ny)] = a;
@@ -111,13 +111,13 @@ SPK_DEV void ta_p2(const P &p, const Dims &dm, MatPtr M, double *__restrict__ zo
     }
     if (r < nx) {
         const MatPtr Ut = M + dm.mU + t.stage * nx * nu;
-        double a = 0.;
+        real a = 0.;
         for (int k = 0; k < nu; ++k) a += Ut[r + k * nx] * ubs[k];
         cq[r] = a - g.xb;
     }
     if (r < nu) {
         const MatPtr Ri = M + dm.mRinv + t.stage * nu * nu;
-        double a = 0.;
+        real a = 0.;
         for (int k = 0; k < nu; ++k) a += Ri[r + k * nu] * ubs[k];
         ce[r] = a;
     }
@@ -127,27 +127,27 @@ SPK_DEV void ta_p2(const P &p, const Dims &dm, MatPtr M, double *__restrict__ zo
 // phase B, part 1: w, dz, the pre-prox value of every owned v entry; publish the partial sums of b'y and of the
 // second-order-cone blocks.  xi / ui / xleaf: this lane's element of x_i, u_i and of the leaf children's x.
 template <class P>
-SPK_DEV void tb_p1(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z, const double *__restrict__ v,
-                   const double *zb, const TeamNode &t, int r, int T, double *S, const double *xsrc, const double *usrc,
-                   const double *xlsrc, int xl_stride, const ProxScal &ps, unsigned flags, TLReg<P> &g) {
+SPK_DEV void tb_p1(const P &p, const Dims &dm, MatPtr M, const real *__restrict__ z, const real *__restrict__ v,
+                   const real *zb, const TeamNode &t, int r, int T, real *S, const real *xsrc, const real *usrc,
+                   const real *xlsrc, int xl_stride, const ProxScal &ps, unsigned flags, TLReg<P> &g) {
     if (!t.active) return;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), m = ny + 2 * d;
     const int i = t.node;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0;
-    const double sg = ps.sigma, isg = noprox ? 1. : ps.inv_sigma;
+    const real sg = ps.sigma, isg = noprox ? 1. : ps.inv_sigma;
     const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb + (dm.nRm > 1 ? t.node * p.ny() : 0);
-    double *red = S + m + nu;   // [(2 + 2 d)][T]
-    double pb0 = 0., pb1 = 0.;
+    real *red = S + m + nu;   // [(2 + 2 d)][T]
+    real pb0 = 0., pb1 = 0.;
     if (r < ny) {
-        const double zbk = zb[dm.zy + i * ny + r], zk = z[dm.zy + i * ny + r];
+        const real zbk = zb[dm.zy + i * ny + r], zk = z[dm.zy + i * ny + r];
         g.wy = wz ? zbk : 2. * zbk + -1. * zk; g.dzy = zbk - zk;
         pb0 = bb[r] * g.wy; pb1 = bb[r] * g.dzy;
     }
     red[0 * T + r] = pb0; red[1 * T + r] = pb1;
-    double sq[2 * P::MAXD];
+    real sq[2 * P::MAXD];
     SPK_UNROLL for (int c = 0; c < 2 * d; ++c) sq[c] = 0.;
     if (r < nx) {
-        const double xi = xsrc[r], zi = z[dm.zx + i * nx + r];
+        const real xi = xsrc[r], zi = z[dm.zx + i * nx + r];
         g.wx = wz ? xi : 2. * xi + -1. * zi; g.dzx = xi - zi; g.xb = xi;
         SPK_UNROLL for (int c = 0; c < d; ++c) {   // v3_j = sqrtQ x_i (implicit_l.jl:226-235)
             const int jn = t.c0 + c - 1;
@@ -158,7 +158,7 @@ SPK_DEV void tb_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
         if (t.kids_leaf)
             SPK_UNROLL for (int c = 0; c < d; ++c) {   // v11 = sqrtQN x_leaf, v14 = x_leaf (implicit_l.jl:288-317)
                 const int j = t.c0 + c, li = j - dm.nn;
-                const double xl = xlsrc[c * xl_stride + r], zk = z[dm.zx + j * nx + r];
+                const real xl = xlsrc[c * xl_stride + r], zk = z[dm.zx + j * nx + r];
                 g.wl[c] = wz ? xl : 2. * xl + -1. * zk; g.dl[c] = xl - zk;
                 g.t11[c] = (sg * (SN[r + r * nx] * g.wl[c]) + v[dm.o11 + li * nx + r]) * isg;
                 g.l11[c] = SN[r + r * nx] * g.dl[c];
@@ -167,7 +167,7 @@ SPK_DEV void tb_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
             }
     }
     if (r < nu) {
-        const double ui = usrc[r], zi = z[dm.zu + i * nu + r];
+        const real ui = usrc[r], zi = z[dm.zu + i * nu + r];
         g.wu = wz ? ui : 2. * ui + -1. * zi; g.dzu = ui - zi; g.ub = ui;
         SPK_UNROLL for (int c = 0; c < d; ++c) {   // v4_j = sqrtR u_i (implicit_l.jl:239-248)
             const int jn = t.c0 + c - 1;
@@ -182,77 +182,77 @@ SPK_DEV void tb_p1(const P &p, const Dims &dm, MatPtr M, const double *__restric
 // phase B, part 2: finish the Moreau step (prox_h_conj!), store vbar, accumulate the residual maxima
 // SPM: the SP driver's inner products with the residual of this evaluation, as in b_local (spock_device.hpp)
 template <class P, int SPM = 0>
-SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ z, const double *__restrict__ v,
-                   const double *zb, double *__restrict__ vo, const TeamNode &t, int r, int T, const double *S,
-                   const ProxScal &ps, unsigned flags, const TLReg<P> &g, double *mx, double *sp = nullptr,
-                   const double *dirz = nullptr, const double *dirv = nullptr) {
+SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const real *__restrict__ z, const real *__restrict__ v,
+                   const real *zb, real *__restrict__ vo, const TeamNode &t, int r, int T, const real *S,
+                   const ProxScal &ps, unsigned flags, const TLReg<P> &g, real *mx, real *sp = nullptr,
+                   const real *dirz = nullptr, const real *dirv = nullptr) {
     if (!t.active) return;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), nxu = nx + nu, m = ny + 2 * d;
     const int i = t.node;
     const bool wz = (flags & F_W_IS_ZBAR) != 0, noprox = (flags & F_NO_PROX) != 0, wx = ps.want_xi;
-    const double sg = ps.sigma, isg = noprox ? 1. : ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
+    const real sg = ps.sigma, isg = noprox ? 1. : ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
     const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb + (dm.nRm > 1 ? t.node * p.ny() : 0);
-    const double *red = S + m + nu;
-    double m1 = mx[0], m2 = mx[1], m3 = mx[2];
-    double sp_z = 0., sp_v = 0., sp_d = 0.;
-    const double gm = ps.gamma;
-    auto acc_z = [&](int iz, double dz, double x1) {
+    const real *red = S + m + nu;
+    real m1 = mx[0], m2 = mx[1], m3 = mx[2];
+    real sp_z = 0., sp_v = 0., sp_d = 0.;
+    const real gm = ps.gamma;
+    auto acc_z = [&](int iz, real dz, real x1) {
         if (SPM >= 1) sp_z += dz * x1;
         if (SPM == 2) sp_d -= dirz[iz] * (dz - sg * (x1 - nig * dz));
     };
-    auto acc_v = [&](int iv, double dv, double x2) {
+    auto acc_v = [&](int iv, real dv, real x2) {
         if (SPM >= 1) sp_v += dv * x2;
         if (SPM == 2) sp_d -= dirv[iv] * (dv - gm * (x2 - nis * dv));
     };
     // ---- v2 (every lane, redundantly: a handful of flops) and v1 (lane r < ny)
-    double bw = 0., bdz = 0.;
+    real bw = 0., bdz = 0.;
     for (int k = 0; k < ny; ++k) { bw += red[0 * T + k]; bdz += red[1 * T + k]; }
-    const double zbs = zb[dm.zs + i], zs_ = z[dm.zs + i];
-    const double ws = wz ? zbs : 2. * zbs + -1. * zs_, dzs = zbs - zs_;
-    double t2 = (sg * (ws - bw) + v[dm.o2 + i]) * isg;
-    const double nv2 = noprox ? t2 : sg * (t2 - (t2 >= 0. ? t2 : 0.));   // implicit_l.jl:849-851
-    const double dv2 = nv2 - v[dm.o2 + i];
-    const double x2 = (dzs - bdz) + nis * dv2;
+    const real zbs = zb[dm.zs + i], zs_ = z[dm.zs + i];
+    const real ws = wz ? zbs : 2. * zbs + -1. * zs_, dzs = zbs - zs_;
+    real t2 = (sg * (ws - bw) + v[dm.o2 + i]) * isg;
+    const real nv2 = noprox ? t2 : sg * (t2 - (t2 >= 0. ? t2 : 0.));   // implicit_l.jl:849-851
+    const real dv2 = nv2 - v[dm.o2 + i];
+    const real x2 = (dzs - bdz) + nis * dv2;
     if (r == 0) {
         vo[dm.o2 + i] = nv2;
         m2 = spk_max_nan(m2, fabs(x2));
-        const double x1s = dv2 + nig * dzs;                            // xi_1 on s_i
+        const real x1s = dv2 + nig * dzs;                            // xi_1 on s_i
         m1 = spk_max_nan(m1, fabs(x1s));
         acc_v(dm.o2 + i, dv2, x2); acc_z(dm.zs + i, dzs, x1s);
         if (wx) m3 = spk_max_nan(m3, fabs(x2 + x1s));
     }
     if (r < ny) {
-        const double t1 = (sg * g.wy + v[i * ny + r]) * isg;
-        double nv1 = t1;
+        const real t1 = (sg * g.wy + v[i * ny + r]) * isg;
+        real nv1 = t1;
         if (!noprox) {
             const int kind = (dm.elem_kind_mask >> (2 * r)) & 3;       // dual-cone kind of this element (implicit_l.jl:833-845)
-            const double pr = kind == 0 ? 0. : (kind == 1 ? (t1 < 0. ? 0. : t1) : (kind == 2 ? (t1 > 0. ? 0. : t1) : t1));
+            const real pr = kind == 0 ? 0. : (kind == 1 ? (t1 < 0. ? 0. : t1) : (kind == 2 ? (t1 > 0. ? 0. : t1) : t1));
             nv1 = sg * (t1 - pr);
         }
         vo[i * ny + r] = nv1;
-        const double dv1 = nv1 - v[i * ny + r];
-        const double x2k = g.dzy + nis * dv1;
+        const real dv1 = nv1 - v[i * ny + r];
+        const real x2k = g.dzy + nis * dv1;
         m2 = spk_max_nan(m2, fabs(x2k));
-        const double x1k = (dv1 - bb[r] * dv2) + nig * g.dzy;
+        const real x1k = (dv1 - bb[r] * dv2) + nig * g.dzy;
         m1 = spk_max_nan(m1, fabs(x1k));
         acc_v(i * ny + r, dv1, x2k); acc_z(dm.zy + i * ny + r, g.dzy, x1k);
         if (wx) m3 = spk_max_nan(m3, fabs((x2k - bb[r] * x2) + x1k));
     }
     // ---- v7: box on (x_i, u_i)
-    double ltx = 0., lxx = 0., ltu = 0., lxu = 0.;
+    real ltx = 0., lxx = 0., ltu = 0., lxu = 0.;
     if (r < nx) {
-        const double vin = v[dm.o7 + i * nxu + r];
-        const double tt = (sg * g.wx + vin) * isg;
-        const double nvv = noprox ? tt : sg * (tt - spk_clamp(tt, dm.x_min, dm.x_max));
+        const real vin = v[dm.o7 + i * nxu + r];
+        const real tt = (sg * g.wx + vin) * isg;
+        const real nvv = noprox ? tt : sg * (tt - spk_clamp(tt, dm.x_min, dm.x_max));
         vo[dm.o7 + i * nxu + r] = nvv;
         ltx = nvv - vin; lxx = g.dzx + nis * ltx;
         m2 = spk_max_nan(m2, fabs(lxx));
         acc_v(dm.o7 + i * nxu + r, ltx, lxx);
     }
     if (r < nu) {
-        const double vin = v[dm.o7 + i * nxu + nx + r];
-        const double tt = (sg * g.wu + vin) * isg;
-        const double nvv = noprox ? tt : sg * (tt - spk_clamp(tt, dm.u_min, dm.u_max));
+        const real vin = v[dm.o7 + i * nxu + nx + r];
+        const real tt = (sg * g.wu + vin) * isg;
+        const real nvv = noprox ? tt : sg * (tt - spk_clamp(tt, dm.u_min, dm.u_max));
         vo[dm.o7 + i * nxu + nx + r] = nvv;
         ltu = nvv - vin; lxu = g.dzu + nis * ltu;
         m2 = spk_max_nan(m2, fabs(lxu));
@@ -261,45 +261,45 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
     // ---- per child: (v6; v3, v4, v5) in SOC(nx + nu + 2)   (implicit_l.jl:854-900, :928-933)
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = t.c0 + c, jn = j - 1;
-        const double zbt = zb[dm.zt + jn], zt_ = z[dm.zt + jn];
-        const double wt = wz ? zbt : 2. * zbt + -1. * zt_, dzt = zbt - zt_;
-        double t6 = (sg * (0.5 * wt) + v[dm.o6 + jn]) * isg, t5 = (sg * (0.5 * wt) + v[dm.o5 + jn]) * isg;
-        double keep = 1., tnew = t6, sc = 1.;      // projected (t; x) = (tnew; sc * x) unless keep
+        const real zbt = zb[dm.zt + jn], zt_ = z[dm.zt + jn];
+        const real wt = wz ? zbt : 2. * zbt + -1. * zt_, dzt = zbt - zt_;
+        real t6 = (sg * (0.5 * wt) + v[dm.o6 + jn]) * isg, t5 = (sg * (0.5 * wt) + v[dm.o5 + jn]) * isg;
+        real keep = 1., tnew = t6, sc = 1.;      // projected (t; x) = (tnew; sc * x) unless keep
         if (!noprox) {
             t5 -= 0.5; t6 += 0.5;
-            double ss = t5 * t5;
+            real ss = t5 * t5;
             for (int k = 0; k < T; ++k) ss += red[(2 + c) * T + k];
-            const double x_norm = sqrt(ss);
+            const real x_norm = sqrt(ss);
             if (x_norm <= t6) { keep = 1.; }
             else if (x_norm <= -t6) { keep = 0.; tnew = 0.; sc = 0.; }
             else { keep = 0.; tnew = (t6 + x_norm) / 2.; sc = tnew / x_norm; }
         }
-        const double p6 = noprox ? t6 : sg * (t6 - (keep != 0. ? t6 : tnew));
-        const double p5 = noprox ? t5 : sg * (t5 - (keep != 0. ? t5 : sc * t5));
-        const double dv6 = p6 - v[dm.o6 + jn], dv5 = p5 - v[dm.o5 + jn];
-        const double x26 = 0.5 * dzt + nis * dv6, x25 = 0.5 * dzt + nis * dv5;
+        const real p6 = noprox ? t6 : sg * (t6 - (keep != 0. ? t6 : tnew));
+        const real p5 = noprox ? t5 : sg * (t5 - (keep != 0. ? t5 : sc * t5));
+        const real dv6 = p6 - v[dm.o6 + jn], dv5 = p5 - v[dm.o5 + jn];
+        const real x26 = 0.5 * dzt + nis * dv6, x25 = 0.5 * dzt + nis * dv5;
         if (r == 0) {
             vo[dm.o6 + jn] = p6; vo[dm.o5 + jn] = p5;
             m2 = spk_max_nan(m2, fabs(x26)); m2 = spk_max_nan(m2, fabs(x25));
-            const double x1t = (0.5 * dv5 + 0.5 * dv6) + nig * dzt;   // xi_1 on tau_j
+            const real x1t = (0.5 * dv5 + 0.5 * dv6) + nig * dzt;   // xi_1 on tau_j
             m1 = spk_max_nan(m1, fabs(x1t));
             acc_v(dm.o6 + jn, dv6, x26); acc_v(dm.o5 + jn, dv5, x25); acc_z(dm.zt + jn, dzt, x1t);
             if (wx) m3 = spk_max_nan(m3, fabs((0.5 * x25 + 0.5 * x26) + x1t));
         }
         if (r < nx) {
-            const double tt = g.t3[c];
-            const double pj = noprox ? tt : sg * (tt - (keep != 0. ? tt : sc * tt));
+            const real tt = g.t3[c];
+            const real pj = noprox ? tt : sg * (tt - (keep != 0. ? tt : sc * tt));
             vo[dm.o3 + jn * nx + r] = pj;
-            const double dv = pj - v[dm.o3 + jn * nx + r], xx = g.l3[c] + nis * dv;
+            const real dv = pj - v[dm.o3 + jn * nx + r], xx = g.l3[c] + nis * dv;
             m2 = spk_max_nan(m2, fabs(xx));
             acc_v(dm.o3 + jn * nx + r, dv, xx);
             ltx += SQ[r + r * nx] * dv; lxx += SQ[r + r * nx] * xx;
         }
         if (r < nu) {
-            const double tt = g.t4[c];
-            const double pj = noprox ? tt : sg * (tt - (keep != 0. ? tt : sc * tt));
+            const real tt = g.t4[c];
+            const real pj = noprox ? tt : sg * (tt - (keep != 0. ? tt : sc * tt));
             vo[dm.o4 + jn * nu + r] = pj;
-            const double dv = pj - v[dm.o4 + jn * nu + r], xx = g.l4[c] + nis * dv;
+            const real dv = pj - v[dm.o4 + jn * nu + r], xx = g.l4[c] + nis * dv;
             m2 = spk_max_nan(m2, fabs(xx));
             acc_v(dm.o4 + jn * nu + r, dv, xx);
             ltu += SR[r + r * nu] * dv; lxu += SR[r + r * nu] * xx;
@@ -307,43 +307,43 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
         // ---- leaf child: (v13; v11, v12) in SOC(nx + 2), v14 in the x box   (implicit_l.jl:752-810, :934-939)
         if (t.kids_leaf) {
             const int li = j - dm.nn;
-            const double zbs2 = zb[dm.zs + j], zs2 = z[dm.zs + j];
-            const double ws2 = wz ? zbs2 : 2. * zbs2 + -1. * zs2, dzs2 = zbs2 - zs2;
-            double t13 = (sg * (0.5 * ws2) + v[dm.o13 + li]) * isg, t12 = (sg * (0.5 * ws2) + v[dm.o12 + li]) * isg;
-            double keep2 = 1., tnew2 = t13, sc2 = 1.;
+            const real zbs2 = zb[dm.zs + j], zs2 = z[dm.zs + j];
+            const real ws2 = wz ? zbs2 : 2. * zbs2 + -1. * zs2, dzs2 = zbs2 - zs2;
+            real t13 = (sg * (0.5 * ws2) + v[dm.o13 + li]) * isg, t12 = (sg * (0.5 * ws2) + v[dm.o12 + li]) * isg;
+            real keep2 = 1., tnew2 = t13, sc2 = 1.;
             if (!noprox) {
                 t12 -= 0.5; t13 += 0.5;
-                double ss = t12 * t12;
+                real ss = t12 * t12;
                 for (int k = 0; k < T; ++k) ss += red[(2 + d + c) * T + k];
-                const double x_norm = sqrt(ss);
+                const real x_norm = sqrt(ss);
                 if (x_norm <= t13) { keep2 = 1.; }
                 else if (x_norm <= -t13) { keep2 = 0.; tnew2 = 0.; sc2 = 0.; }
                 else { keep2 = 0.; tnew2 = (t13 + x_norm) / 2.; sc2 = tnew2 / x_norm; }
             }
-            const double p13 = noprox ? t13 : sg * (t13 - (keep2 != 0. ? t13 : tnew2));
-            const double p12 = noprox ? t12 : sg * (t12 - (keep2 != 0. ? t12 : sc2 * t12));
-            const double dv13 = p13 - v[dm.o13 + li], dv12 = p12 - v[dm.o12 + li];
-            const double x213 = 0.5 * dzs2 + nis * dv13, x212 = 0.5 * dzs2 + nis * dv12;
+            const real p13 = noprox ? t13 : sg * (t13 - (keep2 != 0. ? t13 : tnew2));
+            const real p12 = noprox ? t12 : sg * (t12 - (keep2 != 0. ? t12 : sc2 * t12));
+            const real dv13 = p13 - v[dm.o13 + li], dv12 = p12 - v[dm.o12 + li];
+            const real x213 = 0.5 * dzs2 + nis * dv13, x212 = 0.5 * dzs2 + nis * dv12;
             if (r == 0) {
                 vo[dm.o13 + li] = p13; vo[dm.o12 + li] = p12;
                 m2 = spk_max_nan(m2, fabs(x213)); m2 = spk_max_nan(m2, fabs(x212));
-                const double x1s2 = (0.5 * dv12 + 0.5 * dv13) + nig * dzs2;   // xi_1 on s_leaf
+                const real x1s2 = (0.5 * dv12 + 0.5 * dv13) + nig * dzs2;   // xi_1 on s_leaf
                 m1 = spk_max_nan(m1, fabs(x1s2));
                 acc_v(dm.o13 + li, dv13, x213); acc_v(dm.o12 + li, dv12, x212); acc_z(dm.zs + j, dzs2, x1s2);
                 if (wx) m3 = spk_max_nan(m3, fabs((0.5 * x212 + 0.5 * x213) + x1s2));
             }
             if (r < nx) {
-                const double tt = g.t11[c];
-                const double p11 = noprox ? tt : sg * (tt - (keep2 != 0. ? tt : sc2 * tt));
+                const real tt = g.t11[c];
+                const real p11 = noprox ? tt : sg * (tt - (keep2 != 0. ? tt : sc2 * tt));
                 vo[dm.o11 + li * nx + r] = p11;
-                const double dv11 = p11 - v[dm.o11 + li * nx + r], x211 = g.l11[c] + nis * dv11;
+                const real dv11 = p11 - v[dm.o11 + li * nx + r], x211 = g.l11[c] + nis * dv11;
                 m2 = spk_max_nan(m2, fabs(x211));
-                const double t14 = g.t14[c];
-                const double p14 = noprox ? t14 : sg * (t14 - spk_clamp(t14, dm.x_min, dm.x_max));
+                const real t14 = g.t14[c];
+                const real p14 = noprox ? t14 : sg * (t14 - spk_clamp(t14, dm.x_min, dm.x_max));
                 vo[dm.o14 + li * nx + r] = p14;
-                const double dv14 = p14 - v[dm.o14 + li * nx + r], x214 = g.dl[c] + nis * dv14;
+                const real dv14 = p14 - v[dm.o14 + li * nx + r], x214 = g.dl[c] + nis * dv14;
                 m2 = spk_max_nan(m2, fabs(x214));
-                const double x1 = (dv14 + SN[r + r * nx] * dv11) + nig * g.dl[c];   // x_leaf = v14 + sqrtQN v11
+                const real x1 = (dv14 + SN[r + r * nx] * dv11) + nig * g.dl[c];   // x_leaf = v14 + sqrtQN v11
                 m1 = spk_max_nan(m1, fabs(x1));
                 acc_v(dm.o11 + li * nx + r, dv11, x211); acc_v(dm.o14 + li * nx + r, dv14, x214); acc_z(dm.zx + j * nx + r, g.dl[c], x1);
                 if (wx) m3 = spk_max_nan(m3, fabs((x214 + SN[r + r * nx] * x211) + x1));
@@ -351,13 +351,13 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
         }
     }
     if (r < nx) {
-        const double x1 = ltx + nig * g.dzx;
+        const real x1 = ltx + nig * g.dzx;
         m1 = spk_max_nan(m1, fabs(x1));
         acc_z(dm.zx + i * nx + r, g.dzx, x1);
         if (wx) m3 = spk_max_nan(m3, fabs(lxx + x1));
     }
     if (r < nu) {
-        const double x1 = ltu + nig * g.dzu;
+        const real x1 = ltu + nig * g.dzu;
         m1 = spk_max_nan(m1, fabs(x1));
         acc_z(dm.zu + i * nu + r, g.dzu, x1);
         if (wx) m3 = spk_max_nan(m3, fabs(lxu + x1));
@@ -370,33 +370,33 @@ SPK_DEV void tb_p2(const P &p, const Dims &dm, MatPtr M, const double *__restric
 // ---------------------------------------------------------------------------------------------------
 // LOP for lane teams (see lop_local in spock_sp.hpp): acc[0] += <a, P b>, acc[1] += <a, P b2>, acc[2], acc[3] maxima
 template <class P>
-SPK_DEV void tlop(const P &p, const Dims &dm, MatPtr M, const double *__restrict__ A, const double *__restrict__ Bv,
-                  const double *__restrict__ B2, const TeamNode &t, int r, double gamma, double sigma, double *acc) {
+SPK_DEV void tlop(const P &p, const Dims &dm, MatPtr M, const real *__restrict__ A, const real *__restrict__ Bv,
+                  const real *__restrict__ B2, const TeamNode &t, int r, real gamma, real sigma, double *acc) {
     if (!t.active) return;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), nxu = nx + nu, nz = dm.nz;
     const int i = t.node;
-    const double nig = -1. / gamma, nis = -1. / sigma;
+    const real nig = -1. / gamma, nis = -1. / sigma;
     const MatPtr SQ = M + dm.mSqQ, SR = M + dm.mSqR, SN = M + dm.mSqQN, bb = M + dm.mb + (dm.nRm > 1 ? t.node * p.ny() : 0);
     const int nb = B2 ? 2 : 1;
     for (int which = 0; which < nb; ++which) {
-        const double *b = which ? B2 : Bv, *bz = b, *bv = b + nz;
-        const double *az = A, *av = A ? A + nz : nullptr;
-        double sum = 0., m1 = acc[2], m2 = acc[3];
+        const real *b = which ? B2 : Bv, *bz = b, *bv = b + nz;
+        const real *az = A, *av = A ? A + nz : nullptr;
+        real sum = 0., m1 = acc[2], m2 = acc[3];
         if (r < nx) {
-            const double bx = bz[dm.zx + i * nx + r], b7 = bv[dm.o7 + i * nxu + r];
-            double lt = b7;
+            const real bx = bz[dm.zx + i * nx + r], b7 = bv[dm.o7 + i * nxu + r];
+            real lt = b7;
             if (A) sum += av[dm.o7 + i * nxu + r] * (b7 - sigma * bx);
             m2 = spk_max_nan(m2, fabs(bx + nis * b7));
             SPK_UNROLL for (int c = 0; c < d; ++c) {
                 const int jn = t.c0 + c - 1;
-                const double b3 = bv[dm.o3 + jn * nx + r], l3 = SQ[r + r * nx] * bx;
+                const real b3 = bv[dm.o3 + jn * nx + r], l3 = SQ[r + r * nx] * bx;
                 lt += SQ[r + r * nx] * b3;
                 if (A) sum += av[dm.o3 + jn * nx + r] * (b3 - sigma * l3);
                 m2 = spk_max_nan(m2, fabs(l3 + nis * b3));
                 if (t.kids_leaf) {
                     const int j = t.c0 + c, li = j - dm.nn;
-                    const double bxl = bz[dm.zx + j * nx + r], b11 = bv[dm.o11 + li * nx + r], b14 = bv[dm.o14 + li * nx + r];
-                    const double l11 = SN[r + r * nx] * bxl, ltl = b14 + SN[r + r * nx] * b11;
+                    const real bxl = bz[dm.zx + j * nx + r], b11 = bv[dm.o11 + li * nx + r], b14 = bv[dm.o14 + li * nx + r];
+                    const real l11 = SN[r + r * nx] * bxl, ltl = b14 + SN[r + r * nx] * b11;
                     if (A) sum += az[dm.zx + j * nx + r] * (bxl - gamma * ltl) + av[dm.o11 + li * nx + r] * (b11 - sigma * l11) + av[dm.o14 + li * nx + r] * (b14 - sigma * bxl);
                     m1 = spk_max_nan(m1, fabs(ltl + nig * bxl));
                     m2 = spk_max_nan(m2, fabs(l11 + nis * b11));
@@ -407,13 +407,13 @@ SPK_DEV void tlop(const P &p, const Dims &dm, MatPtr M, const double *__restrict
             m1 = spk_max_nan(m1, fabs(lt + nig * bx));
         }
         if (r < nu) {
-            const double bu = bz[dm.zu + i * nu + r], b7 = bv[dm.o7 + i * nxu + nx + r];
-            double lt = b7;
+            const real bu = bz[dm.zu + i * nu + r], b7 = bv[dm.o7 + i * nxu + nx + r];
+            real lt = b7;
             if (A) sum += av[dm.o7 + i * nxu + nx + r] * (b7 - sigma * bu);
             m2 = spk_max_nan(m2, fabs(bu + nis * b7));
             SPK_UNROLL for (int c = 0; c < d; ++c) {
                 const int jn = t.c0 + c - 1;
-                const double b4 = bv[dm.o4 + jn * nu + r], l4 = SR[r + r * nu] * bu;
+                const real b4 = bv[dm.o4 + jn * nu + r], l4 = SR[r + r * nu] * bu;
                 lt += SR[r + r * nu] * b4;
                 if (A) sum += av[dm.o4 + jn * nu + r] * (b4 - sigma * l4);
                 m2 = spk_max_nan(m2, fabs(l4 + nis * b4));
@@ -421,33 +421,33 @@ SPK_DEV void tlop(const P &p, const Dims &dm, MatPtr M, const double *__restrict
             if (A) sum += az[dm.zu + i * nu + r] * (bu - gamma * lt);
             m1 = spk_max_nan(m1, fabs(lt + nig * bu));
         }
-        const double b2v = bv[dm.o2 + i];
+        const real b2v = bv[dm.o2 + i];
         if (r < ny) {
-            const double by = bz[dm.zy + i * ny + r], b1 = bv[i * ny + r];
-            const double lty = b1 - bb[r] * b2v;
+            const real by = bz[dm.zy + i * ny + r], b1 = bv[i * ny + r];
+            const real lty = b1 - bb[r] * b2v;
             if (A) sum += az[dm.zy + i * ny + r] * (by - gamma * lty) + av[i * ny + r] * (b1 - sigma * by);
             m1 = spk_max_nan(m1, fabs(lty + nig * by));
             m2 = spk_max_nan(m2, fabs(by + nis * b1));
         }
         if (r == 0) {   // scalars of the node: s_i <-> v2, tau_j <-> v5, v6, s_leaf <-> v12, v13
-            const double bs = bz[dm.zs + i];
-            double bdot = 0.;
+            const real bs = bz[dm.zs + i];
+            real bdot = 0.;
             for (int k = 0; k < ny; ++k) bdot += bb[k] * bz[dm.zy + i * ny + k];
-            const double l2 = bs - bdot;
+            const real l2 = bs - bdot;
             if (A) sum += az[dm.zs + i] * (bs - gamma * b2v) + av[dm.o2 + i] * (b2v - sigma * l2);
             m1 = spk_max_nan(m1, fabs(b2v + nig * bs));
             m2 = spk_max_nan(m2, fabs(l2 + nis * b2v));
             SPK_UNROLL for (int c = 0; c < d; ++c) {
                 const int j = t.c0 + c, jn = j - 1;
-                const double bt = bz[dm.zt + jn], b5 = bv[dm.o5 + jn], b6 = bv[dm.o6 + jn];
-                const double lt = 0.5 * b5 + 0.5 * b6, l56 = 0.5 * bt;
+                const real bt = bz[dm.zt + jn], b5 = bv[dm.o5 + jn], b6 = bv[dm.o6 + jn];
+                const real lt = 0.5 * b5 + 0.5 * b6, l56 = 0.5 * bt;
                 if (A) sum += az[dm.zt + jn] * (bt - gamma * lt) + av[dm.o5 + jn] * (b5 - sigma * l56) + av[dm.o6 + jn] * (b6 - sigma * l56);
                 m1 = spk_max_nan(m1, fabs(lt + nig * bt));
                 m2 = spk_max_nan(m2, fabs(l56 + nis * b5)); m2 = spk_max_nan(m2, fabs(l56 + nis * b6));
                 if (t.kids_leaf) {
                     const int li = j - dm.nn;
-                    const double bsl = bz[dm.zs + j], b12 = bv[dm.o12 + li], b13 = bv[dm.o13 + li];
-                    const double lts = 0.5 * b12 + 0.5 * b13, l1213 = 0.5 * bsl;
+                    const real bsl = bz[dm.zs + j], b12 = bv[dm.o12 + li], b13 = bv[dm.o13 + li];
+                    const real lts = 0.5 * b12 + 0.5 * b13, l1213 = 0.5 * bsl;
                     if (A) sum += az[dm.zs + j] * (bsl - gamma * lts) + av[dm.o12 + li] * (b12 - sigma * l1213) + av[dm.o13 + li] * (b13 - sigma * l1213);
                     m1 = spk_max_nan(m1, fabs(lts + nig * bsl));
                     m2 = spk_max_nan(m2, fabs(l1213 + nis * b12)); m2 = spk_max_nan(m2, fabs(l1213 + nis * b13));

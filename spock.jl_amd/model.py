@@ -96,8 +96,11 @@ class Model:
 
     def __init__(self, flat: FlatProblem, options: SolverOptions, batch: int = 1, device: int = 0,
                  L_norm: float | str | None = None, max_iter: int = 0, split_stage: int = 0, graph_iters: int = 0,
-                 lib_path: str | None = None, layout: str | int | None = None):
-        self._lib = _lib.load_library(lib_path)
+                 lib_path: str | None = None, layout: str | int | None = None, dtype: str = "f64"):
+        if dtype not in ("f64", "f32"):
+            raise ValueError("dtype must be 'f64' or 'f32'")
+        self._lib = _lib.load_library(lib_path or (_lib.F32_LIB if dtype == "f32" else None))
+        self.dtype = "f32" if self._lib.spock_real_size() == 4 else "f64"
         self.problem_definition = flat
         self.options = options
         self.batch = int(batch)
@@ -220,7 +223,8 @@ class Model:
 def build_model(scen_tree, cost, dynamics, rms, constraints, solver_options: SolverOptions = SolverOptions(CP, None),
                 **kw) -> Model:
     """model.jl:273-297.  Keyword extensions: batch, device, L_norm, max_iter, split_stage, graph_iters, lib_path, layout
-    ("instance" / "interleaved": how the batch is laid out in HBM; default: interleaved from 64 instances on)."""
+    ("instance" / "interleaved": how the batch is laid out in HBM; default: interleaved from 64 instances on), dtype ("f64", or
+    "f32": libspock_amd_f32.so, the same kernels in single precision -- the reference itself is Float64 only)."""
     if solver_options.algorithm not in (AlgorithmOptions.CP, AlgorithmOptions.SP):
         raise ValueError("This combination of solver options is not supported.")
     return Model(flatten_problem(scen_tree, cost, dynamics, rms, constraints), solver_options, **kw)

@@ -27,8 +27,8 @@ static bool env_on(const char *k) { const char *e = std::getenv(k); return e && 
 template <class P>
 struct EmuExec {
     std::vector<TState<P>> st;
-    std::vector<double> ex, lmv;
-    std::vector<std::array<double, 3>> m;
+    std::vector<real> ex, lmv;
+    std::vector<std::array<real, 3>> m;
     int fl = 0, nthreads_v = 0;
     bool reverse = false;
     EmuExec(int thr, int ex_doubles, size_t nmats) : st(thr), ex((size_t)ex_doubles + 8, 0.), lmv(nmats + 8, 0.), m(thr), nthreads_v(thr), reverse(env_on("SPOCK_EMU_REVERSE")) {}
@@ -38,11 +38,11 @@ struct EmuExec {
         else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t]);
     }
     void barrier() {}
-    double *lds() { return ex.data(); }
-    double *lds_mats() { return lmv.data(); }
+    real *lds() { return ex.data(); }
+    real *lds_mats() { return lmv.data(); }
     int &flag() { return fl; }
-    void stash3(int tid, const double *mx) { m[tid] = {mx[0], mx[1], mx[2]}; }
-    double r3[3] = {0., 0., 0.};
+    void stash3(int tid, const real *mx) { m[tid] = {mx[0], mx[1], mx[2]}; }
+    real r3[3] = {0., 0., 0.};
     int nthreads() const { return nthreads_v; }
     unsigned long long stamps_v[128] = {0};
     unsigned long long *stamp_lds() { return stamps_v; }
@@ -51,15 +51,15 @@ struct EmuExec {
         for (int k = 0; k < 3; ++k) r3[k] = 0.;
         for (int t = 0; t < nthreads_v; ++t) for (int k = 0; k < 3; ++k) r3[k] = spk_max_nan(r3[k], m[t][k]);
     }
-    double red3(int k) const { return r3[k]; }
-    std::vector<std::array<double, 3>> sm3;
-    double s3[3] = {0., 0., 0.};
-    void stash_sum3(int tid, const double *v) { if (sm3.size() != m.size()) sm3.assign(m.size(), {0., 0., 0.}); sm3[tid] = {v[0], v[1], v[2]}; }
+    real red3(int k) const { return r3[k]; }
+    std::vector<std::array<real, 3>> sm3;
+    real s3[3] = {0., 0., 0.};
+    void stash_sum3(int tid, const real *v) { if (sm3.size() != m.size()) sm3.assign(m.size(), {0., 0., 0.}); sm3[tid] = {v[0], v[1], v[2]}; }
     void reduce_sum3() {
         for (int k = 0; k < 3; ++k) s3[k] = 0.;
         for (size_t t = 0; t < sm3.size(); ++t) for (int k = 0; k < 3; ++k) s3[k] += sm3[t][k];
     }
-    double sum3(int k) const { return s3[k]; }
+    real sum3(int k) const { return s3[k]; }
 };
 
 static inline int round64(int t) { return t < 64 ? 64 : ((t + 63) / 64) * 64; }
@@ -107,7 +107,7 @@ static int launch_variant(int mode, const KArgs &a_in) {
 template <class P>
 struct EmuIExec {
     std::vector<IState<P>> st;
-    std::vector<double> ex, rd;
+    std::vector<real> ex, rd;
     int lf[64] = {0};
     int nthreads_v;
     bool reverse;
@@ -118,7 +118,7 @@ struct EmuIExec {
         else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t]);
     }
     void barrier() {}
-    double *lds() { return ex.data(); }
+    real *lds() { return ex.data(); }
     double *red() { return rd.data(); }
     int *live_flags() { return lf; }
     int nthreads() const { return nthreads_v; }
@@ -154,12 +154,12 @@ static int launch_ivariant(int mode, const KArgs &a_in) {
     return 0;
 }
 
-int launch_transpose(double *dst, const double *src, long rows, long cols, long ld_src, long ld_dst, void *) {
+int launch_transpose(real *dst, const real *src, long rows, long cols, long ld_src, long ld_dst, void *) {
     for (long r = 0; r < rows; ++r) for (long c = 0; c < cols; ++c) dst[c * ld_dst + r] = src[r * ld_src + c];
     return 0;
 }
 
-int launch_ilv_collect(double *const *z3, double *const *v2, const Ctl *ctl, long nz, long nv, long bp, int batch, void *) {
+int launch_ilv_collect(real *const *z3, real *const *v2, const Ctl *ctl, long nz, long nv, long bp, int batch, void *) {
     for (int b = 0; b < batch; ++b) {
         const int rp = ctl[b].result_parity;
         if (rp % 3) for (long e = 0; e < nz; ++e) z3[0][e * bp + b] = z3[rp % 3][e * bp + b];
@@ -218,18 +218,18 @@ static int emu_lop(const SpArgs &a) {
         for (int g = 0; g < sp_lop_blocks(dm); ++g) {
             const bool split = dm.t0 > 0, crown = split && g == dm.nsub;
             const long o = (long)inst * a.nr;
-            const double *A = nullptr, *B = nullptr, *B2 = nullptr;
+            const real *A = nullptr, *B = nullptr, *B2 = nullptr;
             if (a.op == SP_LOP_R) { A = a.R + o; B = a.R + o; }
             else if (a.op == SP_LOP_RT) { A = a.RW + o; B = a.RW + o; B2 = a.D + o; }
             else { B = a.DP + o; }
-            double tot[4] = {0., 0., 0., 0.};
+            real tot[4] = {0., 0., 0., 0.};
             if (P::TEAMLOCAL) {
                 int T = 8; while (T < dm.nx || T < dm.nu) T *= 2;
                 const int stages = crown ? dm.t0 + 1 : (split ? dm.sub_stages : dm.N), nl_grp = group_threads(dm.d, stages);
                 for (int li = 0; li < nl_grp; ++li)
                     for (int r = 0; r < T; ++r) {
                         const TeamNode tn = team_node(dm, p.d(), li, nl_grp, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0, stages, crown);
-                        double acc[4] = {0., 0., 0., 0.};
+                        real acc[4] = {0., 0., 0., 0.};
                         tlop(p, dm, (MatPtr)a.mats, A, B, B2, tn, r, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
                         tot[0] += acc[0]; tot[1] += acc[1];
                         tot[2] = spk_max_nan(tot[2], acc[2]); tot[3] = spk_max_nan(tot[3], acc[3]);
@@ -239,12 +239,12 @@ static int emu_lop(const SpArgs &a) {
                 TState<P> s;
                 init_geometry(p, dm, tid, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0,
                               crown ? dm.t0 + 1 : (split ? dm.sub_stages : dm.N), crown, s);
-                double acc[4] = {0., 0., 0., 0.};
+                real acc[4] = {0., 0., 0., 0.};
                 if (s.active) lop_local(p, dm, (MatPtr)a.mats, A, B, B2, s, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
                 tot[0] += acc[0]; tot[1] += acc[1];
                 tot[2] = spk_max_nan(tot[2], acc[2]); tot[3] = spk_max_nan(tot[3], acc[3]);
             }
-            double *dst = a.partL + ((long)inst * a.n_partL + g) * kSpSums;
+            real *dst = a.partL + ((long)inst * a.n_partL + g) * kSpSums;
             for (int k = 0; k < 4; ++k) dst[k] = tot[k];
         }
     }
@@ -259,9 +259,9 @@ int launch_sp(const SpArgs &a, void *) {
             if (done == 1 || (done && a.op != SP_FLAT5)) continue;   // done == 2: the state update of the final iteration still runs
             const SpCtl c = a.sp[inst];
             for (int blk = 0; blk < a.n_partF; ++blk) {
-                double sums[6] = {0., 0., 0., 0., 0., 0.};
+                real sums[6] = {0., 0., 0., 0., 0., 0.};
                 for (long e = blk; e < a.nr; e += a.n_partF) sp_flat_elem(a, c, inst, e, sums);
-                double *dst = a.partF + ((long)inst * a.n_partF + blk) * kSpSums;
+                real *dst = a.partF + ((long)inst * a.n_partF + blk) * kSpSums;
                 if (a.op == SP_FLAT1 || a.op == SP_FLAT2) for (int k = 0; k < 6; ++k) dst[k] = sums[k];
             }
         }
@@ -272,16 +272,16 @@ int launch_sp(const SpArgs &a, void *) {
             Ctl &ctl = a.ctl[inst];
             if (ctl.done) { if (a.op == SP_CTL_A && ctl.done == 2) ctl.done = 1; continue; }
             SpCtl &c = a.sp[inst];
-            const double *pf = a.partF + (long)inst * a.n_partF * kSpSums, *pl = a.partL + (long)inst * a.n_partL * kSpSums;
-            double f[6] = {0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
+            const real *pf = a.partF + (long)inst * a.n_partF * kSpSums, *pl = a.partL + (long)inst * a.n_partL * kSpSums;
+            real f[6] = {0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
             for (int r = 0; r < a.n_partF; ++r) for (int k = 0; k < 6; ++k) f[k] += pf[(long)r * kSpSums + k];
             for (int r = 0; r < a.n_partL; ++r) {
                 l[0] += pl[(long)r * kSpSums]; l[1] += pl[(long)r * kSpSums + 1];
                 m[0] = spk_max_nan(m[0], pl[(long)r * kSpSums + 2]); m[1] = spk_max_nan(m[1], pl[(long)r * kSpSums + 3]);
             }
-            double g2[2] = {0., 0.};
+            real g2[2] = {0., 0.};
             if ((a.op == SP_CTL_A || a.op == SP_CTL_C || a.op == SP_CTL_CD) && a.fused_lop) {
-                const double *pg = a.partG + (long)inst * a.n_partG * kPartialStride;
+                const real *pg = a.partG + (long)inst * a.n_partG * kPartialStride;
                 l[0] = l[1] = 0.; m[0] = m[1] = 0.;
                 for (int r = 0; r < a.n_partG; ++r) {
                     l[0] += -ctl.gamma * pg[(long)r * kPartialStride + 4] - ctl.sigma * pg[(long)r * kPartialStride + 5];
@@ -290,7 +290,7 @@ int launch_sp(const SpArgs &a, void *) {
                     g2[0] = spk_max_nan(g2[0], pg[(long)r * kPartialStride + 3]); g2[1] = spk_max_nan(g2[1], pg[(long)r * kPartialStride + 7]);
                 }
             }
-            double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
+            real *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
             if (a.op == SP_CTL_CD) sp_ctl_cd(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], hist, a.hist_cap);
             else if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0], m[0], m[1]);
             else if (a.op == SP_CTL_B) sp_ctl_b(c, f);
@@ -314,10 +314,10 @@ int launch_sp(const SpArgs &a, void *) {
 int launch_mpc_advance(const MpcArgs &a, void *) {
     const Dims &dm = a.dm;
     for (int inst = 0; inst < a.batch; ++inst) {
-        const double *z = a.z + (long)inst * a.stride_z;
-        double *x0 = a.x0 + (long)inst * dm.nx;
+        const real *z = a.z + (long)inst * a.stride_z;
+        real *x0 = a.x0 + (long)inst * dm.nx;
         const int w = a.w_seq[(long)inst * a.steps + a.t];
-        std::vector<double> xn(dm.nx);
+        std::vector<real> xn(dm.nx);
         for (int r = 0; r < dm.nx; ++r) {
             if (a.t == 0) a.x_traj[((long)inst * (a.steps + 1)) * dm.nx + r] = x0[r];
             xn[r] = mpc_advance_row(dm, (MatPtr)a.mats, z, a.stride_e, x0, w, r);

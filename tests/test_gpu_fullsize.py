@@ -147,3 +147,24 @@ def test_cfg4_mpc_sp_full_size(S, O):
     assert np.max(rel[:10]) <= 1e-9 and np.max(rel) <= 1e-6      # north_star: iterates within 1e-6 relative
     assert np.array_equal(h["backtrack"], ro["hist_backtrack"])
     m1.close()
+
+
+def test_cfg5_fp32_variant(S, O):
+    """BASELINE config 5's fp32 leg: libspock_amd_f32.so (the same kernels compiled with real = float) on the random linear
+    system.  The reference is Float64 only (src/model.jl:304-307), so the tolerance is this build's own: operators within
+    2e-5 (relative to max(1, |ref|_inf)) of the fp64 oracle, a CP solve to tol 1e-3 converging in the oracle's iteration
+    count +- 2 % to an iterate within 2e-3 of it."""
+    specs = S.get_random_linear_specs(9, 64, 16)
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, dtype="f32", L_norm="auto")
+    assert m.dtype == "f32"
+    o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal(flat.nz); v = rng.standard_normal(flat.nv); x0 = np.full(flat.nx, 0.1)
+    zo, vo = m.T(z, v, 0.3, 0.29, x0); zr, vr = o.T(z, v, 0.3, 0.29, x0)
+    assert relerr(zo, zr) <= 2e-5 and relerr(vo, vr) <= 2e-5
+    assert relerr(m.L(z), o.L(z)) <= 2e-6 and relerr(m.L_transpose(v), o.Lt(v)) <= 2e-6
+    r = S.solve_model(m, x0, tol=1e-3); ro = o.solve(x0, tol=1e-3)
+    assert r["status"] == ro["status"] == 0 and abs(r["iterations"] - ro["iterations"]) <= max(2, 0.02 * ro["iterations"])
+    assert relerr(m.solver_state.z, o.z) <= 2e-3
+    m.close()
