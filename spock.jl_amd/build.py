@@ -80,7 +80,7 @@ def build_f32(force: bool = False, verbose: bool = False) -> str:
     cover everything else).  Same C ABI (double at the boundary)."""
     global OUT
     keep, keep_defs = OUT, os.environ.get("SPOCK_BUILD_DEFS")
-    os.environ["SPOCK_BUILD_DEFS"] = "-DSPOCK_REAL=float -cl-single-precision-constant -DSPOCK_STATIC_SHAPES(X)=X(5,2,2,5)"
+    os.environ["SPOCK_BUILD_DEFS"] = "-DSPOCK_REAL=float -cl-single-precision-constant -DSPOCK_STATIC_SHAPES(X)=X(5,2,2,5)X(5,5,2,5)"
     try:
         return build(force=force, verbose=verbose, out=OUT_F32, tmp_name="build_f32")
     finally:

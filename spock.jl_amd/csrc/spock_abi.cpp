@@ -310,12 +310,12 @@ int run_op(spock_handle_s *h, const double *z_in, const double *v_in, const doub
     const Dims &dm = h->bp.dm;
     DeviceGuard guard(h->device);
     RTCHECK(ensure_op_buffers(h));
-    const size_t bz = sizeof(double) * dm.nz, bv = sizeof(double) * dm.nv;
-    if (z_in) RTCHECK(rt::h2d(h->o_z[0], z_in, bz, h->stream)); else RTCHECK(rt::dzero(h->o_z[0], bz, h->stream));
-    if (v_in) RTCHECK(rt::h2d(h->o_v[0], v_in, bv, h->stream)); else RTCHECK(rt::dzero(h->o_v[0], bv, h->stream));
-    if (zbar_in) RTCHECK(rt::h2d(h->o_z[1], zbar_in, bz, h->stream)); else RTCHECK(rt::dzero(h->o_z[1], bz, h->stream));
+    const size_t bz = sizeof(real) * dm.nz, bv = sizeof(real) * dm.nv;
+    if (z_in) RTCHECK(up(h, h->o_z[0], z_in, dm.nz)); else RTCHECK(rt::dzero(h->o_z[0], bz, h->stream));
+    if (v_in) RTCHECK(up(h, h->o_v[0], v_in, dm.nv)); else RTCHECK(rt::dzero(h->o_v[0], bv, h->stream));
+    if (zbar_in) RTCHECK(up(h, h->o_z[1], zbar_in, dm.nz)); else RTCHECK(rt::dzero(h->o_z[1], bz, h->stream));
     RTCHECK(rt::dzero(h->o_v[1], bv, h->stream));
-    if (x0) RTCHECK(rt::h2d(h->o_x0, x0, sizeof(real) * dm.nx, h->stream)); else RTCHECK(rt::dzero(h->o_x0, sizeof(real) * dm.nx, h->stream));
+    if (x0) RTCHECK(up(h, h->o_x0, x0, dm.nx)); else RTCHECK(rt::dzero(h->o_x0, sizeof(real) * dm.nx, h->stream));
     Ctl c = fresh_ctl(h, gamma, sigma, 0., SPOCK_SILENT);
     RTCHECK(rt::h2d(h->o_ctl, &c, sizeof(Ctl), h->stream));
     RTCHECK(launch_iteration(h, true, 0, flags | F_NO_CTL, phase_a, phase_b));
