@@ -513,16 +513,19 @@ def test_emulated_interleaved_equals_instance_major_and_mpc(S, O, emu):
 def test_interleaved_layout_falls_back_or_refuses(S, emu):
     specs = S.get_server_heat_specs(5, 5, 2)
     # SP has no element-major kernels: chosen automatically it falls back, asked for explicitly it is refused
-    m = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, batch=70)
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, batch=1024)
     assert m.sizes.interleaved == 0
     m.close()
     with pytest.raises(S.SpockError):
         S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, batch=70, layout="interleaved")
     # run-time shapes (no compile-time variant) likewise
     specs2 = S.get_server_heat_specs(4, 4, 3, p_ref=[0.2, 0.3, 0.5])
-    m = S.build_model(*specs2, lib_path=emu, batch=64)
+    m = S.build_model(*specs2, lib_path=emu, batch=1024)
     assert m.sizes.interleaved == 0
     m.close()
-    m = S.build_model(*specs, lib_path=emu, batch=64)      # CP, compile-time shape, >= 64 instances: element-major by default
+    m = S.build_model(*specs, lib_path=emu, batch=1024)    # CP, compile-time shape, >= 1024 instances: element-major by default
     assert m.sizes.interleaved == 1
+    m.close()
+    m = S.build_model(*specs, lib_path=emu, batch=64)      # fewer: the instance-major kernels (faster there)
+    assert m.sizes.interleaved == 0
     m.close()

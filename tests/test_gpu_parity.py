@@ -410,8 +410,8 @@ def test_interleaved_layout_matches_oracle(S, O, N, nu, B, kw):
     flat = S.flatten_problem(*specs)
     cap = 120 if N >= 8 else 1200
     x0 = 0.1 * (1 + 0.02 * np.arange(B))[:, None] * np.ones((B, 5)); x0[B // 2] = [-0.1, 0.1, 0.05, 0.0, 0.3]
-    m = S.build_model(*specs, batch=B, max_iter=cap, **kw)
-    assert m.sizes.interleaved == 1                              # >= 64 instances, CP, compile-time shape: chosen by default
+    m = S.build_model(*specs, batch=B, max_iter=cap, layout="interleaved", **kw)
+    assert m.sizes.interleaved == 1
     rs = S.solve_model(m, x0, tol=1e-3)
     Z = m.solver_state.z.copy(); V = m.solver_state.v.copy()
     for b in sorted(set([0, 1, B // 2, 63, 64 if B > 64 else 0, B - 1])):
@@ -439,7 +439,7 @@ def test_interleaved_full_size_cfg2(S, O):
     flat = S.flatten_problem(*specs)
     B = 256
     x0 = 0.1 * (1.0 + 0.001 * np.arange(B))[:, None] * np.ones((B, 5))
-    m = S.build_model(*specs, batch=B, max_iter=48, graph_iters=48)
+    m = S.build_model(*specs, batch=B, max_iter=48, graph_iters=48, layout="interleaved")
     assert m.sizes.interleaved == 1 and m.sizes.fused_iteration == 1
     rs = S.solve_model(m, x0, tol=0.0)
     Z = m.solver_state.z
