@@ -102,6 +102,19 @@ def necessary_bytes(flat):
     return W * ((flat.nz + flat.nv + szy + d) + (flat.nz + flat.nv + d))
 
 
+def lba_necessary_bytes(flat):
+    """Bottom-stage level kernel LBA (spock_ilevel.hpp), per instance and launch, entry by entry (W = 8).  Per node of stage N-2:
+    reads   X: x_i, d_i, z.x_i, z.u_i, v7 | R: zbar.y, z.y, zbar.s_i, z.s_i, v1, v2 | C_c: zbar.tau, z.tau, v3..v6 | L_c: z.x_leaf, v11..v14, zbar.s, z.s
+    writes  X: u_i, vbar.v7, d_i, q_i | R: vbar.v1, v2, next zbar's y, s_ch, tau_ch | C_c: vbar.v3..v6 | L_c: x_leaf, vbar.v11..v14
+    (the roles' re-loads of x_i, d_i, z.x_i, z.u_i hit the L2 and are not counted)."""
+    W, nx, nu, ny, d = 8, flat.nx, flat.nu, flat.ny, flat.d
+    nxu = nx + nu
+    reads = 3 * nxu + (3 * ny + 3) + d * (nxu + 4) + d * (3 * nx + 4)
+    writes = (2 * nxu + nu) + (2 * ny + 1 + 2 * d) + d * (nxu + 2) + d * (3 * nx + 2)
+    n_bottom = flat.nl // d
+    return W * n_bottom * (reads + writes)
+
+
 def lib_fingerprint(path):
     h = hashlib.sha256()
     with open(path, "rb") as f:
@@ -213,14 +226,17 @@ def main(argv=None):
         traffic = traffic_raw = None
         fp = lib_fingerprint(args.lib or slib.DEFAULT_LIB)
         pdir = os.path.join(ROOT, "profiles")
+        pmc_kernels = {}
         for rnd in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
             f = os.path.join(pdir, rnd, f"pmc_b{B}_summary.json")
             if os.path.exists(f):
                 summ = json.load(open(f))
-                k = summ.get("kernels", {}).get("sub_ba" if (fused and dom == "sub_b") else dom)
-                if k and summ.get("lib_sha16") == fp:
-                    traffic = k["hbm_bytes_per_launch_corrected"]; traffic_raw = k.get("hbm_bytes_per_launch_raw")
+                if summ.get("lib_sha16") == fp:
+                    pmc_kernels = summ.get("kernels", {})
                 break
+        k = pmc_kernels.get("sub_ba" if (fused and dom == "sub_b") else dom)
+        if k:
+            traffic = k["hbm_bytes_per_launch_corrected"]; traffic_raw = k.get("hbm_bytes_per_launch_raw")
         kname = {"sub_a": "SUB_A", "sub_b": "SUB_BA" if fused else "SUB_B", "crown": "CROWN", "full": "FULL"}[dom]
         ilv = bool(getattr(model.sizes, "interleaved", 0))
         # `achieved` / `frac`: bytes the kernel must move (entry-by-entry count) over its measured duration.
@@ -228,16 +244,31 @@ def main(argv=None):
         # fused kernel never moves those bytes, so a rate computed on them is not a bandwidth (it would exceed the HBM peak);
         # it is kept as survey_8d_* for comparison with round 1.
         bytes_used = nec if nec else dom_bytes
+        model_txt = "necessary bytes of the fused kernel (reads z, v, zbar's s/tau/y, d; writes zbar, vbar, d)" if nec else "SURVEY 8d"
+        kernel_txt = f"spock {'element-major ' if ilv else ''}group kernel, mode {kname}"
+        seq = model.profile_sequence(24) if ilv else []
+        lba = [(n, lv, ms) for (n, lv, ms) in seq if n == "lba"]
+        if lba:   # level-streaming kernels: the dominant kernel is the bottom stage's LBA; its own necessary bytes
+            dom_ms = lba[0][2]
+            bytes_used = B * lba_necessary_bytes(flat)
+            model_txt = "necessary bytes of the bottom-stage kernel LBA (bench.py: lba_necessary_bytes)"
+            kernel_txt = "spock_ilevel_kernel, mode LBA (bottom stage: forward step + phase B + next phase A + backward step)"
+            k = pmc_kernels.get("lba")
+            traffic = k["hbm_bytes_per_launch_corrected"] if k else None
+            traffic_raw = k.get("hbm_bytes_per_launch_raw") if k else None
         ach = bytes_used / (dom_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": f"spock {'element-major ' if ilv else ''}group kernel, mode {kname}",
+        roofline = {"bound": "hbm", "kernel": kernel_txt,
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_raw": traffic_raw,
-                    "bytes_model": "necessary bytes of the fused kernel (reads z, v, zbar's s/tau/y, d; writes zbar, vbar, d)" if nec else "SURVEY 8d",
+                    "bytes_model": model_txt,
                     "bytes_per_launch": bytes_used,
                     "frac_measured": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "frac_measured_raw": round(traffic_raw / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic_raw else None,
                     "survey_8d_bytes_per_launch": dom_bytes, "survey_8d_rate_GBps": round(achieved, 1),
-                    "avg_launch_ms": round(dom_ms, 5), "launches_timed": prof[dom][1], "lib_sha16": fp,
+                    "avg_launch_ms": round(dom_ms, 5), "launches_timed": 24 if lba else prof[dom][1], "lib_sha16": fp,
                     "all_kernels_avg_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1]},
+                    "iteration_launches_ms": [[n, lv, round(ms, 5)] for (n, lv, ms) in seq],
+                    "whole_iteration_necessary_bytes": B * necessary_bytes(flat),
                     "whole_iteration_frac": round(B * necessary_bytes(flat) * n_gpus / (elapsed / (M * args.steps)) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4)}
     model.close()
 

@@ -182,6 +182,9 @@ int spock_get_timing(spock_handle_t h, double *iter_ms_avg, int32_t *iters_timed
  * HIP event before and after every kernel launch on the handle's stream.  avg_ms / launches: [4], average
  * duration and launch count per kernel kind: 0 subtree phase A, 1 crown, 2 subtree phase B, 3 whole-tree kernel. */
 int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_t *launches);
+/* the same measurement per launch of one CP iteration, in launch order: kernel mode (spock_internal.hpp: GroupMode), its layer
+ * of groups / tree stage, average duration over the `reps` iterations; *n receives the launches per iteration (cap: array sizes) */
+int spock_profile_sequence(spock_handle_t h, int32_t reps, int32_t *modes, int32_t *levels, double *avg_ms, int32_t cap, int32_t *n);
 /* measurement aid: clock stamps (shader clock, 100 MHz wall clock) written by workgroup 0 of instance 0 during the
  * last spock_profile_kernels run with SPOCK_AMD_DEBUG_FLAGS including 512; out: [3 kernels][64 stamps][2]. */
 int spock_debug_stamps(spock_handle_t h, uint64_t *out);

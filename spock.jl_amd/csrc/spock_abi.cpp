@@ -175,7 +175,13 @@ int launch_cp_iteration(spock_handle_s *h, int k, unsigned flags = 0, void *stre
         if (e == 0) e = launch_group(MODE_CROWN, a, stream);
         for (int lv = 1; lv <= dm.n_lv - 2 && e == 0; ++lv) { a.grp_level = lv; e = launch_group(MODE_I_DOWN, a, stream); }
         a.grp_level = 0;
-        if (e == 0) e = launch_group(MODE_SUB_BA, a, stream);
+        if (!dm.ilv_stream) { if (e == 0) e = launch_group(MODE_SUB_BA, a, stream); return e; }
+        // level-streaming kernels (spock_ilevel.hpp) for the stages t0 .. N-2: phase B top-down, the bottom stage fused with the
+        // next phase A and the backward step, then the next phase A + backward step bottom-up
+        for (int t = dm.t0; t <= dm.N - 3 && e == 0; ++t) { a.grp_level = t; e = launch_group(MODE_LB, a, stream); }
+        a.grp_level = dm.N - 2;
+        if (e == 0) e = launch_group(MODE_LBA, a, stream);
+        for (int t = dm.N - 3; t >= dm.t0 && e == 0; --t) { a.grp_level = t; e = launch_group(MODE_LA, a, stream); }
         return e;
     }
     int e = 0;
@@ -207,7 +213,11 @@ int launch_cp_iterations(spock_handle_s *h, int G) {
 }
 int cp_prologue(spock_handle_s *h, unsigned flags = 0) {
     if (!h->fused) return 0;
-    int e = launch_group(MODE_SUB_A, make_args(h, false, 0, flags), h->stream);
+    int e = 0;
+    if (h->ilv && h->bp.dm.ilv_stream) {
+        KArgs a = make_args(h, false, 0, flags);
+        for (int t = h->bp.dm.N - 2; t >= h->bp.dm.t0 && e == 0; --t) { a.grp_level = t; e = launch_group(MODE_LA0, a, h->stream); }
+    } else e = launch_group(MODE_SUB_A, make_args(h, false, 0, flags), h->stream);
     if (e == 0 && h->ilv) e = launch_group(MODE_ICROWN_A, make_args(h, false, 0, flags), h->stream);
     return e;
 }
@@ -555,7 +565,9 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         // (buffer addressing: 32-bit byte offsets inside an array)
         long nvv = 0; { long nn_ = (nl - 1) / (d - 1); nvv = nn_ * ny + nn_ + (long)(nx + nu + 2) * (n - 1) + nn_ * (nx + nu) + nl * (2L * nx + 2); }
         const bool small = nvv * (((long)(h->batch + 63) / 64) * 64) * 8 < (1L << 32) - 4096;
-        const bool fits = small && isplit >= 1 && isplit <= N - 2 && (long)group_threads(d, N - isplit) * nx * 64 * 8 <= 56 * 1024;
+        // (the bottom-group kernels keep a subtree's sweep slots in LDS; the level-streaming kernels have no such limit)
+        const bool stream_lv = !(std::getenv("SPOCK_AMD_ILV_STREAM") && std::getenv("SPOCK_AMD_ILV_STREAM")[0] == '0');
+        const bool fits = small && isplit >= 1 && isplit <= N - 2 && (stream_lv || (long)group_threads(d, N - isplit) * nx * 64 * 8 <= 56 * 1024);
         msg = fits ? host_build(hp, isplit, h->bp, unsupported, h->batch) : std::string("subtree does not fit the element-major kernels' LDS slots");
         if (!msg.empty() && layout == 2) { delete h; return fail(SPOCK_ERR_UNSUPPORTED, msg); }
         if (!msg.empty()) want_ilv = false;   // chosen automatically: fall back to the instance-major kernels
@@ -585,7 +597,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         if ((e = dev_alloc(h, &h->d_z[0], B * dm.nz)) || (e = dev_alloc(h, &h->d_v[0], B * dm.nv))) return bail(e, "hipMalloc(staging)");
         for (int k = 0; k < 3; ++k) if ((e = dev_alloc(h, &h->i_z[k], W * dm.nz))) return bail(e, "hipMalloc(state)");
         for (int k = 0; k < 2; ++k) if ((e = dev_alloc(h, &h->i_v[k], W * dm.nv))) return bail(e, "hipMalloc(state)");
-        if ((e = dev_alloc(h, &h->i_cq, W * (size_t)(group_threads(dm.d, dm.t0 + 1) + dm.nsub) * dm.nx))) return bail(e, "hipMalloc(state)");
+        if ((e = dev_alloc(h, &h->i_cq, W * (size_t)dm.nn * dm.nx))) return bail(e, "hipMalloc(state)");   // q of every non-leaf node
         h->stage_valid = true;
         {   // tile groups: at least four tiles per group, at most four groups
             const int tiles = (int)(h->bpad / 64);
@@ -612,7 +624,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
             return bail(e, "hipMalloc(SP state)");
     }
     h->hist_cap = h->max_iter + 2;
-    const size_t n_part = h->ilv ? (size_t)(h->bpad / 64) * (size_t)(dm.nsub + dm.n_crown_groups) * 3 * 64
+    const size_t n_part = h->ilv ? (size_t)(h->bpad / 64) * (size_t)(dm.n_bslots + dm.n_crown_groups) * 3 * 64
                                  : B * (dm.nsub + 1) * kPartialStride;
     if ((e = dev_alloc(h, &h->d_dbuf, W * dm.nn * dm.nu)) || (e = dev_alloc(h, &h->d_qroot, W * dm.nsub * dm.nx)) ||
         (e = dev_alloc(h, &h->d_cbuf, W * (size_t)(group_threads(dm.d, dm.t0 + 1) + 1) * (dm.nx + dm.nu))) ||
@@ -964,7 +976,19 @@ int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_
     return SPOCK_OK;
 }
 
+static int profile_impl(spock_handle_t h, int32_t reps, double *avg_ms, int32_t *launches, int32_t *seq_modes, int32_t *seq_levels,
+                        double *seq_ms, int32_t seq_cap, int32_t *seq_n);
 int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_t *launches) {
+    if (!avg_ms) return fail(SPOCK_ERR_BAD_ARG, "bad argument");
+    return profile_impl(h, reps, avg_ms, launches, nullptr, nullptr, nullptr, 0, nullptr);
+}
+int spock_profile_sequence(spock_handle_t h, int32_t reps, int32_t *modes, int32_t *levels, double *avg_ms, int32_t cap, int32_t *n) {
+    if (!modes || !levels || !avg_ms || !n) return fail(SPOCK_ERR_BAD_ARG, "bad argument");
+    double kinds[4];
+    return profile_impl(h, reps, kinds, nullptr, modes, levels, avg_ms, cap, n);
+}
+static int profile_impl(spock_handle_t h, int32_t reps, double *avg_ms, int32_t *launches, int32_t *seq_modes, int32_t *seq_levels,
+                        double *seq_ms, int32_t seq_cap, int32_t *seq_n) {
     if (!h || !avg_ms || reps < 1) return fail(SPOCK_ERR_BAD_ARG, "bad argument");
     if (h->alg != SPOCK_ALG_CP) return fail(SPOCK_ERR_UNSUPPORTED, "kernel profiling is implemented for CP handles");
     DeviceGuard guard(h->device);
@@ -982,14 +1006,25 @@ int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_
     if (const char *e = std::getenv("SPOCK_AMD_DEBUG_FLAGS")) dbg = (unsigned)std::atoi(e);
     std::vector<int> seq, seq_it, seq_lv;   // (mode, iteration, layer of mid groups) of every launch, in order
     auto push = [&](int mode, int it, int lv = 0) { seq.push_back(mode); seq_it.push_back(it); seq_lv.push_back(lv); };
-    if (split && h->fused) { push(MODE_SUB_A, 0); if (h->ilv) push(MODE_ICROWN_A, 0); }
+    const Dims &pdm = h->bp.dm;
+    const bool stream_lv = h->ilv && pdm.ilv_stream;
+    if (split && h->fused) {
+        if (stream_lv) for (int t = pdm.N - 2; t >= pdm.t0; --t) push(MODE_LA0, 0, t);
+        else push(MODE_SUB_A, 0);
+        if (h->ilv) push(MODE_ICROWN_A, 0);
+    }
+    const size_t n_prologue = seq.size();
     for (int it = 0; it < reps; ++it) {
         if (!split) { push(MODE_FULL, it); continue; }
         if (!h->fused) push(MODE_SUB_A, it);
-        if (h->ilv) for (int lv = h->bp.dm.n_lv - 2; lv >= 1; --lv) push(MODE_I_UP, it, lv);
+        if (h->ilv) for (int lv = pdm.n_lv - 2; lv >= 1; --lv) push(MODE_I_UP, it, lv);
         push(MODE_CROWN, it);
-        if (h->ilv) for (int lv = 1; lv <= h->bp.dm.n_lv - 2; ++lv) push(MODE_I_DOWN, it, lv);
-        push(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), it);
+        if (h->ilv) for (int lv = 1; lv <= pdm.n_lv - 2; ++lv) push(MODE_I_DOWN, it, lv);
+        if (stream_lv) {
+            for (int t = pdm.t0; t <= pdm.N - 3; ++t) push(MODE_LB, it, t);
+            push(MODE_LBA, it, pdm.N - 2);
+            for (int t = pdm.N - 3; t >= pdm.t0; --t) push(MODE_LA, it, t);
+        } else push(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), it);
     }
     std::vector<void *> ev(seq.size() * 2, nullptr);
     for (auto &e : ev) RTCHECK(rt::event_create(&e));
@@ -1003,15 +1038,27 @@ int spock_profile_kernels(spock_handle_t h, int32_t reps, double *avg_ms, int32_
     RTCHECK(rt::sync(h->stream));
     double sum[4] = {0., 0., 0., 0.};
     int cnt[4] = {0, 0, 0, 0};
+    // per launch of ONE iteration (the last one's sequence): average over the iterations
+    const size_t per_it = reps > 0 ? (seq.size() - n_prologue) / (size_t)reps : 0;
+    std::vector<double> it_sum(per_it, 0.);
     for (size_t k = 0; k < seq.size(); ++k) {
         float ms = 0.f;
         RTCHECK(rt::event_elapsed(&ms, ev[2 * k], ev[2 * k + 1]));
+        if (k >= n_prologue && per_it) it_sum[(k - n_prologue) % per_it] += ms;
         // (element-major regime: the crown's node-local kernels count with the crown, kind 1)
-        const int kind = (seq[k] == MODE_SUB_A || seq[k] == MODE_ICROWN_A) ? 0 : (seq[k] == MODE_CROWN || seq[k] == MODE_I_UP || seq[k] == MODE_I_DOWN) ? 1 : seq[k] == MODE_FULL ? 3 : 2;
+        // (level-streaming kernels: the bottom stage's LBA is kind 2, the other stages' LB / LA count with the crown)
+        const int kind = (seq[k] == MODE_SUB_A || seq[k] == MODE_ICROWN_A || seq[k] == MODE_LA0) ? 0
+                         : (seq[k] == MODE_CROWN || seq[k] == MODE_I_UP || seq[k] == MODE_I_DOWN || seq[k] == MODE_LB || seq[k] == MODE_LA) ? 1 : seq[k] == MODE_FULL ? 3 : 2;
         sum[kind] += ms; cnt[kind] += 1;
     }
     for (auto e : ev) rt::event_destroy(e);
     for (int q = 0; q < 4; ++q) { avg_ms[q] = cnt[q] ? sum[q] / cnt[q] : 0.; if (launches) launches[q] = cnt[q]; }
+    if (seq_n) {
+        *seq_n = (int32_t)per_it;
+        for (size_t k = 0; k < per_it && (int32_t)k < seq_cap; ++k) {
+            seq_modes[k] = seq[n_prologue + k]; seq_levels[k] = seq_lv[n_prologue + k]; seq_ms[k] = it_sum[k] / reps;
+        }
+    }
     // leave a consistent state behind: the iterate after `reps` iterations goes back to slot 0
     if (h->ilv) {
         if (reps % 3) RTCHECK(rt::d2d(h->i_z[0], h->i_z[reps % 3], (size_t)h->bpad * h->bp.dm.nz * sizeof(real), h->stream));

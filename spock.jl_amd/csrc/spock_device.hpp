@@ -369,8 +369,8 @@ SPK_DEV void a_local_g(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZO zo, 
 // second half of phase A: S2 on [y_i; s_ch; tau_ch] = vec (its part of the next zbar goes to zo), then the node-local terms of
 // the S1 recursion c_i -> s.xb, e_i -> s.ub from xbar, ubar (the leaves' xbar stays in s.xl)
 template <class P, class ZO>
-SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s, const real *xbar, const real *ubar, const real *vec) {
-    const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny();
+SPK_DEV void a_finish_s2(const P &p, const Dims &dm, MatPtr M, ZO zo, const TState<P> &s, const real *vec) {
+    const int d = p.d(), ny = p.ny();
     const int i = s.node;
     // S2: projector onto ker [E' -I -I ; F' 0 0] applied to [y_i; s_ch; tau_ch]  (implicit_l.jl:708-726)
     const int m = ny + 2 * d;
@@ -382,7 +382,10 @@ SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s,
         else if (r < ny + d) zo[dm.zs + s.c0 + (r - ny)] = t;
         else zo[dm.zt + s.c0 + (r - ny - d) - 1] = t;
     }
-    spk_block_fence<ZO>();
+}
+template <class P>
+SPK_DEV void a_finish_ce(const P &p, const Dims &dm, MatPtr M, TState<P> &s, const real *xbar, const real *ubar) {
+    const int nx = p.nx(), nu = p.nu();
     // node-local terms of the S1 recursion
     const MatPtr Ut = M + dm.mU + s.stage * nx * nu;
     const MatPtr Ri = M + dm.mRinv + s.stage * nu * nu;
@@ -396,6 +399,12 @@ SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s,
         SPK_UNROLL for (int k = 0; k < nu; ++k) t += Ri[r + k * nu] * ubar[k];
         s.ub[r] = t;
     }
+}
+template <class P, class ZO>
+SPK_DEV void a_finish(const P &p, const Dims &dm, MatPtr M, ZO zo, TState<P> &s, const real *xbar, const real *ubar, const real *vec) {
+    a_finish_s2(p, dm, M, zo, s, vec);
+    spk_block_fence<ZO>();
+    a_finish_ce(p, dm, M, s, xbar, ubar);
 }
 
 // plain-pointer form (instance-major layout): the restrict qualifiers tell the compiler that the iterate it reads and the

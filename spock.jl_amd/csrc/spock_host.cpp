@@ -149,6 +149,14 @@ int choose_split_stage(int N, int d, int nx, int nu, int batch) {
 // Element-major batched regime: a subtree workgroup keeps one q / x slot of nx x 64 doubles per non-leaf node in LDS; subtrees
 // of up to ~40 KB of slots leave room for three workgroups per CU.  The crown (stages <= t0) exchanges through global memory.
 int choose_split_stage_ilv(int N, int d, int nx) {
+    if (!(std::getenv("SPOCK_AMD_ILV_STREAM") && std::getenv("SPOCK_AMD_ILV_STREAM")[0] == '0')) {
+        // level-streaming kernels below the split: a small crown (one top group, no mid layers) and everything else streamed.
+        // Measured on MI355X (config 2, 2048 instances): split 3 / 4 / 5 / 6 / 8 -> 2.37 / 2.37 / 2.49 / 2.48 / 2.49 ms per iteration.
+        // (The instance-major kernels of the operator entry points share the split: their subtrees must fit one workgroup.)
+        int t0 = N - 2 < 4 ? N - 2 : 4;
+        while (t0 < N - 2 && group_threads(d, N - t0) > 512) ++t0;
+        return t0 < 1 ? 1 : t0;
+    }
     int S = 2;
     while (S + 1 <= N - 1 && (long)group_threads(d, S + 1) * nx * 64 * 8 <= 40 * 1024) ++S;
     return N - S;
@@ -161,7 +169,16 @@ static int ilv_group_span(int d, int nx) {
     return S - 1;
 }
 
-IlvGeo ilv_geometry(int mode, const Dims &dm, int level) {
+// level-streaming kernels: waves per workgroup and LDS exchange rows (role waves hand their partial results to the finishing
+// waves through rows of 64 doubles, double-buffered over the nodes of the chunk)
+int ilevel_waves(int mode, const Dims &dm) { return mode == MODE_LBA ? 2 + 2 * dm.d : (mode == MODE_LB ? 2 + dm.d : 4); }   // X, R, C_c (, L_c)
+int ilevel_ex_doubles(int mode, const Dims &dm, int want_xi) {
+    if (mode == MODE_LBA) return 2 * lba_exchange_rows(dm.nx, dm.nu, dm.d, want_xi != 0) * 64;
+    if (mode == MODE_LB) return 2 * lb_exchange_rows(dm.nx, dm.nu, dm.d, want_xi != 0) * 64;
+    return 0;
+}
+
+IlvGeo ilv_geometry(int mode, const Dims &dm, int level, int want_xi) {
     IlvGeo g;
     const int d = dm.d, nx = dm.nx;
     const int sub_nl = group_threads(d, dm.sub_stages), crown_nl = group_threads(d, dm.t0 + 1);
@@ -174,13 +191,24 @@ IlvGeo ilv_geometry(int mode, const Dims &dm, int level) {
     if (mode == MODE_FINALIZE) { g.threads = 64; g.grid_x = 1; }
     else if (mode == MODE_ICROWN_A) g.grid_x = g.n_cchunks;
     else if (mode == MODE_SUB_A || mode == MODE_SUB_BA) { g.grid_x = dm.nsub; g.ex_doubles = sub_nl * nx * 64; }
+    else if (mode == MODE_LB || mode == MODE_LBA || mode == MODE_LA || mode == MODE_LA0) {   // `level` = the tree stage
+        const int chunk = dm.ls_chunk_t[level] > 0 ? dm.ls_chunk_t[level] : 1;
+        g.grid_x = (ipow(d, level) + chunk - 1) / chunk;
+        g.ls_chunk_k = chunk;
+        g.ex_doubles = ilevel_ex_doubles(mode, dm, want_xi);
+        g.threads = 64 * ilevel_waves(mode, dm);
+        g.ls_cnt = ipow(d, level); g.ls_first = dm.first[level]; g.ls_first_child = dm.first[level + 1];
+        g.ls_slot = dm.ilv_stream ? dm.ls_slot0[level] : 0;
+    }
     else {   // CROWN (top group, level 0), I_UP / I_DOWN (mid groups of `level`)
         const int lv = mode == MODE_CROWN ? 0 : level;
         g.grid_x = ipow(d, dm.lv_root[lv]);
         g.ex_doubles = group_threads(d, dm.lv_root[lv + 1] - dm.lv_root[lv] + 1) * nx * 64;
     }
-    // [exchange slots][maxima: waves x 3 x 64][64 live flags]
-    g.lds_bytes = (size_t)g.ex_doubles * 8 + (size_t)(g.threads / 64) * 3 * 64 * 8 + 64 * 4 + 64;
+    // [exchange slots][maxima: waves x 3 x 64][64 live flags]; level kernels: the maxima reuse the exchange rows (spock_ilevel.hpp)
+    const size_t red = (size_t)(g.threads / 64) * 3 * 64 * 8;
+    const bool lvk = (mode == MODE_LB || mode == MODE_LBA || mode == MODE_LA || mode == MODE_LA0);
+    g.lds_bytes = (lvk ? ((size_t)g.ex_doubles * 8 > red ? (size_t)g.ex_doubles * 8 : red) : (size_t)g.ex_doubles * 8 + red) + 64 * 4 + 64;
     return g;
 }
 
@@ -350,6 +378,26 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
         for (int k = 0; k < n; ++k) dm.lv_root[k] = roots[n - 1 - k];
         dm.n_crown_groups = 0;
         for (int k = 0; k + 1 < n; ++k) dm.n_crown_groups += ipow(d, dm.lv_root[k]);
+        // level-streaming kernels for the stages t0 .. N-2 (spock_ilevel.hpp); SPOCK_AMD_ILV_STREAM=0: the bottom-group kernels
+        dm.ilv_stream = t0 > 0 ? 1 : 0;
+        if (const char *e = std::getenv("SPOCK_AMD_ILV_STREAM")) dm.ilv_stream = (t0 > 0 && e[0] != '0') ? 1 : 0;
+        // nodes per workgroup: up to ls_chunk on the wide stages (amortises the workgroup's start), fewer on the narrow ones so that
+        // a launch has at least ~2 workgroups per CU (512) over the batch's tiles
+        dm.ls_chunk = 16;
+        if (const char *e = std::getenv("SPOCK_AMD_ILV_CHUNK")) { dm.ls_chunk = std::atoi(e); if (dm.ls_chunk < 1) dm.ls_chunk = 1; }
+        dm.n_bslots = dm.nsub;
+        if (dm.ilv_stream) {
+            const long tiles = ((long)batch + 63) / 64;
+            int slot = 0;
+            for (int t = t0; t <= N - 2; ++t) {
+                long c = (long)ipow(d, t) * tiles / 512;
+                if (c < 1) c = 1;
+                if (c > dm.ls_chunk) c = dm.ls_chunk;
+                dm.ls_chunk_t[t] = (int)c;
+                dm.ls_slot0[t] = slot; slot += (ipow(d, t) + (int)c - 1) / (int)c;
+            }
+            dm.n_bslots = slot;
+        }
     }
 
     // ---- offline Riccati recursion (implicit_l.jl:46-97), per stage --------------------------------

@@ -49,11 +49,21 @@ constexpr bool kFuseNextA = true;
 constexpr bool kFuseNextA = false;
 #endif
 
+// role waves of the level-streaming kernels (spock_ilevel.hpp): what a role carries from the part in front of the workgroup's
+// barrier to its finishing part behind it
+template <class P>
+struct LvRole {
+    real xi[P::MAXNX], ui[P::MAXNU];                     // X: x_i, u_i of the node
+    real dzx[P::MAXNX], dzu[P::MAXNU];                   // X: dz = zbar - z on them
+    real nv7[P::MAXNX + P::MAXNU], dv7[P::MAXNX + P::MAXNU], lx7[P::MAXNX + P::MAXNU];   // X: vbar.v7, its dv and xi_2
+    real vecy[P::MAXNY];                                 // R: the y part of (-gamma) L'vbar + zbar
+};
 template <class P>
 struct IState {
     TState<P> s;
     real mx[4];   // xi_1, xi_2, xi maxima and the NaN poison accumulator (spk_resmax)
     bool live;
+    LvRole<P> lr;
 };
 
 SPK_DEV int igroup_nonleaf(int d, int stages) {   // non-leaf nodes of a complete d-ary tree with `stages` stages
@@ -72,12 +82,26 @@ SPK_DEV void igroup_body(X &x, const KArgs &a, const real *zin_, const real *vin
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu;
     const long bp = a.bp, t64 = (long)tile * 64;
     const int nW = x.nthreads() / 64;
-    const int n_groups = dm.nsub + dm.n_crown_groups;
+    const int n_groups = dm.n_bslots + dm.n_crown_groups;   // partial slots: bottom part first, then the crown groups
     const MatPtr M = (MatPtr)a.mats;
     double *partials = a.partials + (long)tile * n_groups * 3 * 64;   // [group][xi1, xi2, xi][lane]
 
     // ---- control: which lanes (instances) are live?  CROWN / FINALIZE also run the pending termination test, one lane each
     if (MODE == MODE_CROWN || MODE == MODE_FINALIZE) {
+        // the workgroups' partial maxima of the previous iteration: every wave reduces a share of the slots (four independent
+        // chains of loads in flight per lane), wave 0 combines the waves' results
+        x.each([&](int tid, IState<P> &st) SPK_ILAMBDA {
+            const int lane = tid & 63, wave = tid >> 6;
+            double m[3][4] = {{0., 0., 0., 0.}, {0., 0., 0., 0.}, {0., 0., 0., 0.}};
+            int gg = wave;
+            for (; gg + 3 * nW < n_groups; gg += 4 * nW)
+                for (int u = 0; u < 4; ++u)
+                    for (int k = 0; k < 3; ++k) m[k][u] = spk_max_nan(m[k][u], partials[((long)(gg + u * nW) * 3 + k) * 64 + lane]);
+            for (; gg < n_groups; gg += nW)
+                for (int k = 0; k < 3; ++k) m[k][0] = spk_max_nan(m[k][0], partials[((long)gg * 3 + k) * 64 + lane]);
+            for (int k = 0; k < 3; ++k) x.red()[(wave * 3 + k) * 64 + lane] = spk_max_nan(spk_max_nan(m[k][0], m[k][1]), spk_max_nan(m[k][2], m[k][3]));
+        });
+        x.barrier();
         x.each([&](int tid, IState<P> &st) SPK_ILAMBDA {
             if (tid >= 64) return;
             const int lane = tid, inst = tile * 64 + lane;
@@ -87,8 +111,8 @@ SPK_DEV void igroup_body(X &x, const KArgs &a, const real *zin_, const real *vin
                 const CtlSnap snap = ctl_snapshot(ctl);
                 double m[3] = {0., 0., 0.};
                 if (snap.pending && !snap.done)
-                    for (int gg = 0; gg < n_groups; ++gg)
-                        for (int k = 0; k < 3; ++k) m[k] = spk_max_nan(m[k], partials[((long)gg * 3 + k) * 64 + lane]);
+                    for (int w = 0; w < nW; ++w)
+                        for (int k = 0; k < 3; ++k) m[k] = spk_max_nan(m[k], x.red()[(w * 3 + k) * 64 + lane]);
                 double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
                 fin = ctl_prologue(ctl, snap, m[0], m[1], m[2], hist, a.hist_cap, a.parity, MODE != MODE_FINALIZE);
             }
@@ -299,7 +323,7 @@ SPK_DEV void igroup_body(X &x, const KArgs &a, const real *zin_, const real *vin
         }
         // partial residual maxima: bottom groups in slots 0 .. nsub - 1, crown groups behind them in the order of their launch
         int slot = g;
-        if (!bottom_grp) { slot = dm.nsub; for (int k = 0; k < lv; ++k) { int c = 1; for (int q = 0; q < dm.lv_root[k]; ++q) c *= d; slot += c; } slot += g; }
+        if (!bottom_grp) { slot = dm.n_bslots; for (int k = 0; k < lv; ++k) { int c = 1; for (int q = 0; q < dm.lv_root[k]; ++q) c *= d; slot += c; } slot += g; }
         reduce_maxima(slot);
     };
 

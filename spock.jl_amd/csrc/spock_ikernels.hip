@@ -17,6 +17,10 @@ struct GpuIExec {
     template <class F>
     __device__ __forceinline__ void each(F &&f) { f((int)threadIdx.x, st); }
     __device__ __forceinline__ void barrier() { __syncthreads(); }
+    // role waves (spock_ilevel.hpp): the body holds the barrier itself, once on every wave-uniform path
+    template <class F>
+    __device__ __forceinline__ void phased(F &&f) { f((int)threadIdx.x, st, true, true); }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ real *lds() { return ex; }
     __device__ __forceinline__ double *red() { return rd; }
     __device__ __forceinline__ int *live_flags() { return lf; }
@@ -42,9 +46,10 @@ spock_igroup_kernel(const KArgs a, const real *__restrict__ zin, const real *__r
 
 template <class P>
 static int launch_ivariant(int mode, const KArgs &a_in, hipStream_t st) {
-    const IlvGeo g = ilv_geometry(mode, a_in.dm, a_in.grp_level);
+    const IlvGeo g = ilv_geometry(mode, a_in.dm, a_in.grp_level, a_in.want_xi);
     KArgs a = a_in;
     a.ex_doubles = g.ex_doubles; a.cchunk = g.cchunk; a.n_cchunks = g.n_cchunks;
+    a.ls_cnt = g.ls_cnt; a.ls_first = g.ls_first; a.ls_first_child = g.ls_first_child; a.ls_slot = g.ls_slot; a.ls_chunk_k = g.ls_chunk_k;
 
     const dim3 grid(g.grid_x, (unsigned)(a.n_tiles > 0 ? a.n_tiles : a.bp / 64)), block(g.threads);
     const size_t lds = g.lds_bytes;
@@ -117,7 +122,10 @@ int launch_ilv_collect(real *const *z3, real *const *v2, const Ctl *ctl, long nz
 }
 
 
+int launch_ilevel(int mode, const KArgs &a, void *stream);   // spock_lkernels.hip
+
 int launch_igroup(int mode, const KArgs &a, void *stream) {
+    if (mode == MODE_LB || mode == MODE_LBA || mode == MODE_LA || mode == MODE_LA0) return launch_ilevel(mode, a, stream);
     hipStream_t st = (hipStream_t)stream;
     const Dims &dm = a.dm;
     const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;

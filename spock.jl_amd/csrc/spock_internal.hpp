@@ -50,6 +50,13 @@ struct Dims {
     int mSweep, sw_stride, sw_oW, sw_oV, sw_oABK, sw_oK;
     // element-major regime: hierarchy of groups (spock_igroup.hpp): root stages of the layers, top (0) first, bottom (t0) last
     int n_lv, lv_root[8], n_crown_groups;
+    // element-major regime, level-streaming kernels (spock_ilevel.hpp) for the stages t0 .. N-2: one launch per tree stage, a
+    // workgroup works on ls_chunk consecutive nodes of the stage and owns one slot of residual partials
+    int ilv_stream;              // 1: stages >= t0 run as level kernels (LB / LBA / LA) instead of the bottom-group kernels
+    int ls_chunk;                // nodes of a stage per workgroup: upper bound (wide stages)
+    int ls_chunk_t[kMaxStages];  // ... per stage: narrow stages take fewer nodes per workgroup so that the launch still fills the chip
+    int ls_slot0[kMaxStages];    // first partial slot of every streamed stage
+    int n_bslots;                // partial slots of the bottom part (old kernels: nsub); the crown groups' slots follow
     int mA;          // A_w, d matrices (closed-loop state update of the MPC loop)
     int diag_costs;  // every sqrtQ / sqrtR / sqrtQN is diagonal -> element-wise products in the kernels
 };
@@ -127,6 +134,7 @@ struct KArgs {
     int want_xi;                // element-major regime: LOG-mode CP (combined residual xi, cp.jl:83-86) selects the kernel variant
     int grp_level;              // element-major regime, I_UP / I_DOWN: the layer of mid groups this launch works on
     int tile0, n_tiles;         // element-major regime: the launch covers tiles tile0 .. tile0 + n_tiles - 1 (n_tiles 0 = all)
+    int ls_cnt, ls_first, ls_first_child, ls_slot, ls_chunk_k;   // level kernels (grp_level = the stage): filled by the launcher from IlvGeo
 };
 
 // ---- SP (SuperMann + Anderson) driver: plain data shared by the kernels (spock_sp.hpp) and the driver ----
@@ -176,7 +184,13 @@ enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, 
                  MODE_SUB_B_LAT = 8,   // SUB_B of the single-instance regime: the leaf-children blocks of phase B on an idle wave
                  N_GROUP_MODES = 9,
                  // element-major regime only (spock_igroup.hpp): the node-local phases of the crown's nodes, chunked over workgroups
-                 MODE_ICROWN_A = 9, MODE_I_UP = 10, MODE_I_DOWN = 11 };
+                 MODE_ICROWN_A = 9, MODE_I_UP = 10, MODE_I_DOWN = 11,
+                 // element-major regime, level-streaming kernels (spock_ilevel.hpp); KArgs::grp_level = the tree stage of the launch
+                 MODE_LB = 12,    // forward step + phase B of one non-bottom stage (top-down)
+                 MODE_LBA = 13,   // bottom stage (children = leaves): forward step, phase B, next phase A, backward step
+                 MODE_LA = 14,    // next phase A + backward step of one non-bottom stage (bottom-up), on (zbar, vbar) -> znext
+                 MODE_LA0 = 15,   // prologue: phase A + backward step of iteration 0 on (z, v) -> zbar, any streamed stage
+                 N_ALL_MODES = 16 };
 
 // ---- host build step (spock_host.cpp) -------------------------------------------------------------
 struct HostProblem {
@@ -206,8 +220,19 @@ int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tre
 
 // element-major batched regime: split stage (subtrees of at most `max_sub_stages` stages, LDS-bound), launch geometry
 int choose_split_stage_ilv(int N, int d, int nx);
-struct IlvGeo { int threads, grid_x, cchunk, n_cchunks; size_t lds_bytes; int ex_doubles; };
-IlvGeo ilv_geometry(int mode, const Dims &dm, int level = 0);
+struct IlvGeo {
+    int threads, grid_x, cchunk, n_cchunks; size_t lds_bytes; int ex_doubles;
+    int ls_cnt = 0, ls_first = 0, ls_first_child = 0, ls_slot = 0, ls_chunk_k = 1;   // level kernels: nodes of the stage, its first node, first node of the next stage, first partial slot
+};
+IlvGeo ilv_geometry(int mode, const Dims &dm, int level = 0, int want_xi = 0);
+// level-streaming kernels (spock_ilevel.hpp): role waves per workgroup, rows (64 doubles each) of ONE LDS exchange buffer
+// (the kernels double-buffer it over the nodes of a chunk).  LBA rows: per child, role C_c [L'dv | L'vbar | L'xi_2 on (x_i, u_i) | tau_c],
+// role L_c [W_c q_c | V_c q_c | s_c];  LB rows: per child, role C_c [L'dv | L'xi_2 on (x_i, u_i)]
+int ilevel_waves(int mode, const Dims &dm);
+// (the L'xi_2 rows exist in the LOG-mode kernel variants only: want_xi)
+constexpr int lba_exchange_rows(int nx, int nu, int d, bool wx) { return d * ((wx ? 3 : 2) * (nx + nu) + 1) + d * (nx + nu + 1); }
+constexpr int lb_exchange_rows(int nx, int nu, int d, bool wx) { return d * (wx ? 2 : 1) * (nx + nu); }
+int ilevel_ex_doubles(int mode, const Dims &dm, int want_xi);
 
 // ---- kernel launchers (spock_kernels.hip) ---------------------------------------------------------
 // Each returns a hipError_t cast to int.  `stream` is a hipStream_t.

@@ -185,6 +185,16 @@ class Model:
         _lib.check(self._lib, self._lib.spock_profile_kernels(self._h, int(reps), _ptr(ms), _ptr(n)))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(("sub_a", "crown", "sub_b", "full"))}
 
+    MODE_NAMES = {0: "full", 1: "sub_a", 2: "crown", 3: "sub_b", 5: "sub_ba", 8: "sub_b_lat", 9: "crown_a", 10: "i_up", 11: "i_down",
+                  12: "lb", 13: "lba", 14: "la", 15: "la0"}
+
+    def profile_sequence(self, reps: int = 20):
+        """Average HIP-event duration (ms) of every launch of one CP iteration, in launch order: [(kernel, level, avg_ms)]."""
+        cap = 64
+        modes = np.zeros(cap, dtype=np.int32); lv = np.zeros(cap, dtype=np.int32); ms = np.zeros(cap); n = C.c_int32(0)
+        _lib.check(self._lib, self._lib.spock_profile_sequence(self._h, int(reps), _ptr(modes), _ptr(lv), _ptr(ms), cap, C.byref(n)))
+        return [(self.MODE_NAMES.get(int(modes[k]), str(int(modes[k]))), int(lv[k]), float(ms[k])) for k in range(min(n.value, cap))]
+
     # ---- operator-level seam (single instance): L!, L_transpose!, prox_f!, prox_h_conj!, spock_dot
     def L(self, z):
         z = np.ascontiguousarray(z, dtype=np.float64); out = np.empty(self.sizes.nv)

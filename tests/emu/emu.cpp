@@ -16,6 +16,7 @@
 
 #include "../../spock.jl_amd/csrc/spock_group.hpp"
 #include "../../spock.jl_amd/csrc/spock_igroup.hpp"
+#include "../../spock.jl_amd/csrc/spock_ilevel.hpp"
 #include "../../spock.jl_amd/csrc/spock_sp.hpp"
 #include "../../spock.jl_amd/csrc/spock_team_local.hpp"
 #include "../../spock.jl_amd/csrc/spock_rt.hpp"
@@ -38,6 +39,15 @@ struct EmuExec {
         else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t]);
     }
     void barrier() {}
+    // role waves: every thread up to the barrier, then every thread behind it
+    template <class F>
+    void phased(F &&f) {
+        for (int ph = 0; ph < 2; ++ph) {
+            if (!reverse) for (int t = 0; t < nthreads_v; ++t) f(t, st[t], ph == 0, ph == 1);
+            else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t], ph == 0, ph == 1);
+        }
+    }
+    void sync() {}
     real *lds() { return ex.data(); }
     real *lds_mats() { return lmv.data(); }
     int &flag() { return fl; }
@@ -118,6 +128,15 @@ struct EmuIExec {
         else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t]);
     }
     void barrier() {}
+    // role waves: every thread up to the barrier, then every thread behind it
+    template <class F>
+    void phased(F &&f) {
+        for (int ph = 0; ph < 2; ++ph) {
+            if (!reverse) for (int t = 0; t < nthreads_v; ++t) f(t, st[t], ph == 0, ph == 1);
+            else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t], ph == 0, ph == 1);
+        }
+    }
+    void sync() {}
     real *lds() { return ex.data(); }
     double *red() { return rd.data(); }
     int *live_flags() { return lf; }
@@ -136,11 +155,24 @@ static void run_iblocks(const KArgs &a, int gx, int thr) {
         }
 }
 
+template <class P, int MODE, bool WX = false>
+static void run_lblocks(const KArgs &a, int gx, int thr, const real *zin, const real *vin, real *zout, real *vout, real *znext) {
+    const bool rev = env_on("SPOCK_EMU_REVERSE_BLOCKS");
+    const int t_lo = a.n_tiles > 0 ? a.tile0 : 0, t_hi = a.n_tiles > 0 ? a.tile0 + a.n_tiles : (int)(a.bp / 64);
+    for (int tile = t_lo; tile < t_hi; ++tile)
+        for (int gi = 0; gi < gx; ++gi) {
+            const int g = rev ? gx - 1 - gi : gi;
+            EmuIExec<P> x(thr, a.ex_doubles);
+            ilevel_body<P, MODE, WX>(x, a, zin, vin, zout, vout, znext, tile, g);
+        }
+}
+
 template <class P>
 static int launch_ivariant(int mode, const KArgs &a_in) {
     KArgs a = a_in;
-    const IlvGeo g = ilv_geometry(mode, a.dm, a.grp_level);
+    const IlvGeo g = ilv_geometry(mode, a.dm, a.grp_level, a.want_xi);
     a.ex_doubles = g.ex_doubles; a.cchunk = g.cchunk; a.n_cchunks = g.n_cchunks;
+    a.ls_cnt = g.ls_cnt; a.ls_first = g.ls_first; a.ls_first_child = g.ls_first_child; a.ls_slot = g.ls_slot; a.ls_chunk_k = g.ls_chunk_k;
     switch (mode) {
         case MODE_SUB_A: run_iblocks<P, MODE_SUB_A>(a, g.grid_x, g.threads); break;
         case MODE_CROWN: if (a.want_xi) run_iblocks<P, MODE_CROWN, true>(a, g.grid_x, g.threads); else run_iblocks<P, MODE_CROWN>(a, g.grid_x, g.threads); break;
@@ -149,6 +181,10 @@ static int launch_ivariant(int mode, const KArgs &a_in) {
         case MODE_SUB_BA: if (a.want_xi) run_iblocks<P, MODE_SUB_BA, true>(a, g.grid_x, g.threads); else run_iblocks<P, MODE_SUB_BA>(a, g.grid_x, g.threads); break;
         case MODE_I_DOWN: if (a.want_xi) run_iblocks<P, MODE_I_DOWN, true>(a, g.grid_x, g.threads); else run_iblocks<P, MODE_I_DOWN>(a, g.grid_x, g.threads); break;
         case MODE_FINALIZE: run_iblocks<P, MODE_FINALIZE>(a, g.grid_x, g.threads); break;
+        case MODE_LB: if (a.want_xi) run_lblocks<P, MODE_LB, true>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, nullptr); else run_lblocks<P, MODE_LB>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, nullptr); break;
+        case MODE_LBA: if (a.want_xi) run_lblocks<P, MODE_LBA, true>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next); else run_lblocks<P, MODE_LBA>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next); break;
+        case MODE_LA: run_lblocks<P, MODE_LA>(a, g.grid_x, g.threads, nullptr, nullptr, a.z_out, a.v_out, a.z_next); break;
+        case MODE_LA0: run_lblocks<P, MODE_LA0>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, nullptr, nullptr); break;
         default: return 1;
     }
     return 0;

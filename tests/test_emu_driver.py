@@ -450,11 +450,16 @@ def test_unsupported_inputs(S, emu):
 
 # ---- element-major ("interleaved") batched regime: one lane per instance, one wave per tree node (spock_igroup.hpp) -----------
 @pytest.mark.parametrize("N,nu,B,kw", [(5, 5, 3, {}), (7, 2, 3, {}), (7, 5, 66, {}), (8, 2, 4, {"split_stage": 5}),
-                                       (10, 5, 2, {"split_stage": 8})])
+                                       (10, 5, 2, {"split_stage": 8}), (8, 2, 70, {"split_stage": 2}),
+                                       (8, 5, 3, {"split_stage": 4, "stream": "0"}), (7, 5, 66, {"stream": "0"})])
 def test_emulated_interleaved_layout_matches_oracle(S, O, emu, monkeypatch, N, nu, B, kw):
     """The element-major kernels against the oracle: different instances stop at different iterations (finished lanes freeze),
     partial tiles (B not a multiple of 64), two tiles, one / two / three layers of groups (split 5 of N = 8: layers [0, 1, 5];
-    split 8 of N = 10: [0, 4, 8]), tile groups on separate streams, warm start, LOG-mode kernel variant, set_state / reset."""
+    split 8 of N = 10: [0, 4, 8]), tile groups on separate streams, warm start, LOG-mode kernel variant, set_state / reset.
+    Below the split stage the level-streaming kernels with their role waves (spock_ilevel.hpp; split 2 of N = 8: five streamed
+    stages under a three-node crown); "stream": "0" = the bottom-group kernels instead."""
+    kw = dict(kw)
+    monkeypatch.setenv("SPOCK_AMD_ILV_STREAM", kw.pop("stream", "1"))
     monkeypatch.setenv("SPOCK_AMD_ILV_TGROUPS", "2")
     specs = S.get_server_heat_specs(N, 5, 2, nu=nu)
     flat = S.flatten_problem(*specs)

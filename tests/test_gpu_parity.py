@@ -402,10 +402,14 @@ def test_sp_batch_matches_single_and_lop_sequence(S, O, monkeypatch):
 
 
 # ---- element-major ("interleaved") batched regime (spock_igroup.hpp): one lane per instance, one wave per tree node -----------
-@pytest.mark.parametrize("N,nu,B,kw", [(7, 5, 70, {}), (8, 2, 64, {"split_stage": 5}), (10, 5, 130, {})])
-def test_interleaved_layout_matches_oracle(S, O, N, nu, B, kw):
+@pytest.mark.parametrize("N,nu,B,kw", [(7, 5, 70, {}), (8, 2, 64, {"split_stage": 5}), (10, 5, 130, {}), (9, 2, 70, {"split_stage": 2}),
+                                       (10, 5, 130, {"stream": "0"})])
+def test_interleaved_layout_matches_oracle(S, O, N, nu, B, kw, monkeypatch):
     """Element-major kernels on the GPU against the oracle: partial tiles, several tiles, instances that stop at different
-    iterations, warm start + LOG-mode kernel variant, bitwise repeatability."""
+    iterations, warm start + LOG-mode kernel variant, bitwise repeatability.  Level-streaming kernels below the split stage
+    (spock_ilevel.hpp); "stream": "0" = the bottom-group kernels instead."""
+    kw = dict(kw)
+    monkeypatch.setenv("SPOCK_AMD_ILV_STREAM", kw.pop("stream", "1"))
     specs = S.get_server_heat_specs(N, 5, 2, nu=nu)
     flat = S.flatten_problem(*specs)
     cap = 120 if N >= 8 else 1200

@@ -9,7 +9,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def main():
-    obj = os.path.join(ROOT, "spock.jl_amd", "build", os.environ.get("KOBJ", "spock_kernels.hip.o"))
+    k = os.environ.get("KOBJ", "spock_kernels.hip.o")
+    obj = k if os.path.isabs(k) else os.path.join(ROOT, "spock.jl_amd", "build", k)
     d = tempfile.mkdtemp()
     fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
     subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj])

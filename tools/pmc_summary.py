@@ -19,7 +19,14 @@ MODES = {"1": "sub_a", "2": "crown", "3": "sub_b", "5": "sub_ba", "0": "full"}
 IMODES = {"1": "sub_a", "2": "crown_top", "5": "sub_ba", "9": "crown_a", "10": "crown_up", "11": "crown_down", "4": "finalize"}
 
 
+LMODES = {"12": "lb", "13": "lba", "14": "la", "15": "la0"}   # level-streaming kernels (spock_ilevel.hpp)
+
+
 def kind(name):
+    if "spock_ilevel_kernel" in name:      # spock_ilevel_kernel<StaticDims<...>, MODE, WX>: LB / LA of all streamed stages pooled
+        import re
+        m = re.search(r">,\s*(\d+),\s*(true|false)>", name)
+        return LMODES.get(m.group(1)) if m else None
     if "spock_igroup_kernel" in name:      # element-major regime: spock_igroup_kernel<StaticDims<...>, MODE, WX>
         import re
         m = re.search(r">,\s*(\d+),\s*(true|false)>", name)
