@@ -599,9 +599,13 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         for (int k = 0; k < 2; ++k) if ((e = dev_alloc(h, &h->i_v[k], W * dm.nv))) return bail(e, "hipMalloc(state)");
         if ((e = dev_alloc(h, &h->i_cq, W * (size_t)dm.nn * dm.nx))) return bail(e, "hipMalloc(state)");   // q of every non-leaf node
         h->stage_valid = true;
-        {   // tile groups: at least four tiles per group, at most four groups
+        {   // tile groups = parallel branches of the captured graph, each with its own chain of kernels over a share of the tiles.
+            // Bottom-group kernels: at least four tiles per group, at most four groups (one group's latency-bound crown chain
+            // overlaps the others' bottom kernel).  Level-streaming kernels: ONE group -- their launches want all the tiles, and
+            // measured on MI355X four branches help only under some HIP runtimes (ROCm 7.2: 2.52 -> 2.30 ms per iteration on one
+            // box, no change on another; the 7.0 runtime a PyTorch process brings along: 2.68 -> 3.1 ms)
             const int tiles = (int)(h->bpad / 64);
-            h->n_tg = tiles >= 16 ? 4 : (tiles >= 8 ? 2 : 1);
+            h->n_tg = h->bp.dm.ilv_stream ? 1 : (tiles >= 16 ? 4 : (tiles >= 8 ? 2 : 1));
             if (const char *e2 = std::getenv("SPOCK_AMD_ILV_TGROUPS")) { h->n_tg = std::atoi(e2); if (h->n_tg < 1) h->n_tg = 1; if (h->n_tg > tiles) h->n_tg = tiles; if (h->n_tg > 8) h->n_tg = 8; }
             if (h->n_tg > 1) {
                 if ((e = rt::event_create(&h->ev_fork))) return bail(e, "hipEventCreate");
