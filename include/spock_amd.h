@@ -102,6 +102,11 @@ typedef struct {
                            * shapes), 1 = instance-major z[b][nz] (one thread per tree node), 2 = element-major z[e][batch]
                            * (one lane per instance, one wave per tree node).  Invisible at this boundary: every array that
                            * crosses it is instance-major. */
+    int32_t sp_variant;   /* SP only.  0: run_sp! / anderson! exactly as the reference has them, defects included (no-op line search
+                           * sp.jl:439, coefficients written into row 1 of R anderson.jl:86); 1: the corrected variant -- least-squares
+                           * Anderson and a line search that shortens the step (no reference counterpart; measures what the defects cost) */
+    int32_t sp_max_backtrack; /* sp_variant 1: candidates tried after the first, 0 -> run_sp!'s MAX_BACKTRACK_COUNT = 8 (sp.jl:371) */
+    int32_t reserved_;
 } spock_options_t;
 
 typedef struct {

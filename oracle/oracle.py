@@ -59,6 +59,7 @@ def lib():
         L.orc_get_L_norm.restype = C.c_double
         L.orc_get_L_norm.argtypes = [C.c_void_p]
         L.orc_set_L_norm.argtypes = [C.c_void_p, C.c_double]
+        L.orc_set_sp_variant.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_L.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_Lt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double]
@@ -85,7 +86,9 @@ class Oracle:
     """One reference-style model (CPOCK or SPOCK) on the CPU.  State persists between solves,
     exactly like the Julia model struct (warm start = leftover state)."""
 
-    def __init__(self, flat, algorithm: int = CP):
+    def __init__(self, flat, algorithm: int = CP, sp_variant: int = 0, sp_max_backtrack: int = 0):
+        """sp_variant 0: run_sp! / anderson! exactly as the reference has them (bug-compatible); 1: the corrected variant
+        (least-squares Anderson, working line search) that spock_options_t.sp_variant = 1 selects on the GPU."""
         self.flat = flat
         self._keep = flat
         pr = _Problem(flat.N, flat.d, flat.nx, flat.nu, flat.ny, _p(flat.A), _p(flat.B), flat.nQ, flat.nR, flat.nQN,
@@ -100,6 +103,8 @@ class Oracle:
         self.n, self.nn, self.nl, self.nz, self.nv, self.ny = (int(x) for x in sz)
         assert self.nz == flat.nz and self.nv == flat.nv
         self.algorithm = algorithm
+        if sp_variant:
+            lib().orc_set_sp_variant(self.h, int(sp_variant), int(sp_max_backtrack))
 
     def __del__(self):
         if getattr(self, "h", None):

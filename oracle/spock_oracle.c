@@ -76,6 +76,7 @@ typedef struct {
     int n_cones, *ck, *cd;
     double x_min, x_max, u_min, u_max;
     double L_norm;
+    int sp_variant, sp_max_backtrack;   /* 0 = the reference's run_sp! as it stands; 1 = corrected Anderson + working line search (below) */
     /* build-step products, stored per stage (identical for every node of a stage
        because ricatti_offline uses only A_w, B_w and the uniform tree shape) */
     double *P;    /* N stages x nx*nx            */
@@ -834,10 +835,84 @@ static void anderson(orc *o, int iter) {
     for (size_t i = 0; i < nv; i++) o->dv[i] = -o->rv[i] - o->aa_wsp[nz + i];
 }
 
+/* ---------------------------------------------------------------- corrected variant (sp_variant = 1; no reference counterpart)
+ * What the reference's anderson! / run_sp! would compute without their defects:
+ *   - Anderson: gamma = argmin |r - MR gamma|_2 over the min(iter, 3) columns present, by the normal equations MR'MR gamma = MR'r
+ *     (3 x 3 Cholesky; a column whose pivot falls below 1e-14 of its diagonal entry is dropped), d = -r - MP gamma.  The
+ *     reference orthogonalises the new column against the stored ones but writes the coefficients into row 1 of R instead of
+ *     column 1 and divides by column norms that should be 1 (anderson.jl:76-99).
+ *   - line search: tau <- beta tau after a rejected candidate (the reference discards the result of perform_linesearch!, sp.jl:439,
+ *     and re-evaluates the same candidate nine times).
+ * K0 stays disabled as in the reference (sp.jl:80).  The GPU option spock_options_t.sp_variant = 1 implements exactly this. */
+void orc_set_sp_variant(orc *o, int variant, int max_backtrack) { o->sp_variant = variant; o->sp_max_backtrack = max_backtrack > 0 ? max_backtrack : 8; }
+
+/* gamma of the normal equations G gamma = rhs on the leading m x m block; G symmetric, column-major 3 x 3 */
+static void ls3_solve(int m, const double *G, const double *rhs, double *g) {
+    double L[9] = {0}, y[3] = {0, 0, 0};
+    int valid[3] = {0, 0, 0};
+    for (int j = 0; j < m; j++) {
+        double s = G[j + 3 * j];
+        for (int k = 0; k < j; k++) if (valid[k]) s -= L[j + 3 * k] * L[j + 3 * k];
+        if (!(s > 1e-14 * G[j + 3 * j])) continue;
+        valid[j] = 1;
+        L[j + 3 * j] = sqrt(s);
+        for (int i = j + 1; i < m; i++) {
+            double t = G[i + 3 * j];
+            for (int k = 0; k < j; k++) if (valid[k]) t -= L[i + 3 * k] * L[j + 3 * k];
+            L[i + 3 * j] = t / L[j + 3 * j];
+        }
+    }
+    for (int j = 0; j < m; j++) {
+        if (!valid[j]) continue;
+        double t = rhs[j];
+        for (int k = 0; k < j; k++) if (valid[k]) t -= L[j + 3 * k] * y[k];
+        y[j] = t / L[j + 3 * j];
+    }
+    for (int j = 2; j >= 0; j--) {
+        g[j] = 0.;
+        if (j >= m || !valid[j]) continue;
+        double t = y[j];
+        for (int k = j + 1; k < m; k++) if (valid[k]) t -= L[k + 3 * j] * g[k];
+        g[j] = t / L[j + 3 * j];
+    }
+}
+
+static void anderson_ls(orc *o, int iter) {
+    size_t nz = o->nz, nv = o->nv, nr = nz + nv;
+    double *MP = o->MP, *MR = o->MR, *g = o->aa_gamma;
+    for (int j = 1; j >= 0; j--) memcpy(MP + (size_t)(j + 1) * nr, MP + (size_t)j * nr, sizeof(double) * nr);
+    for (int j = 1; j >= 0; j--) memcpy(MR + (size_t)(j + 1) * nr, MR + (size_t)j * nr, sizeof(double) * nr);
+    for (size_t i = 0; i < nz; i++) { MR[i] = o->delta_rz[i]; MP[i] = o->delta_z[i] - MR[i]; }
+    for (size_t i = 0; i < nv; i++) { MR[nz + i] = o->delta_rv[i]; MP[nz + i] = o->delta_v[i] - MR[nz + i]; }
+    for (size_t i = 0; i < nz; i++) o->aa_wsp[i] = o->rz[i];
+    for (size_t i = 0; i < nv; i++) o->aa_wsp[nz + i] = o->rv[i];
+    const int m = iter < 3 ? iter : 3;
+    double G[9], rhs[3];
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b <= a; b++) {
+            double s = 0.;
+            for (size_t i = 0; i < nr; i++) s += MR[i + (size_t)a * nr] * MR[i + (size_t)b * nr];
+            G[a + 3 * b] = s; G[b + 3 * a] = s;
+        }
+        double s = 0.;
+        for (size_t i = 0; i < nr; i++) s += MR[i + (size_t)a * nr] * o->aa_wsp[i];
+        rhs[a] = s;
+    }
+    ls3_solve(m, G, rhs, g);
+    for (size_t i = 0; i < nr; i++) {
+        double s = 0.;
+        for (int j = 0; j < 3; j++) s += MP[i + (size_t)j * nr] * g[j];
+        o->aa_wsp[i] = s;
+    }
+    for (size_t i = 0; i < nz; i++) o->dz[i] = -o->rz[i] - o->aa_wsp[i];
+    for (size_t i = 0; i < nv; i++) o->dv[i] = -o->rv[i] - o->aa_wsp[nz + i];
+}
+
 /* ---------------------------------------------------------------- SP (sp.jl:358-469) */
 static void run_sp(orc *o, int max_iter, double tol, int verbose, double gamma, double sigma, orc_hist *h, orc_result *res) {
     const double c1 = 0.99, q = 0.99, sigma_k2 = 0.1, lambda_sp = 1.;
-    const int MAX_BACKTRACK = 8;
+    const int MAX_BACKTRACK = (o->sp_variant == 1 && o->sp_max_backtrack > 0) ? o->sp_max_backtrack : 8;
+    const double beta = 0.5;                                                                         /* sp.jl:370 */
     int nz = o->nz, nv = o->nv;
     int iter = 0, evals = 0, conv = 0, broyden_k = 0;
     double rnorm, rtilde_norm, r_safe = INFINITY, tau;
@@ -850,7 +925,8 @@ static void run_sp(orc *o, int max_iter, double tol, int verbose, double gamma, 
         for (int i = 0; i < nv; i++) o->delta_rv[i] = o->rv[i] - o->rv_old[i];
         memcpy(o->z_old, o->z, sizeof(double) * nz); memcpy(o->v_old, o->v, sizeof(double) * nv);    /* :232-255 */
         memcpy(o->rz_old, o->rz, sizeof(double) * nz); memcpy(o->rv_old, o->rv, sizeof(double) * nv);
-        broyden_k += 1; anderson(o, broyden_k);                                                      /* models/spock.jl:212-224 */
+        broyden_k += 1;                                                                              /* models/spock.jl:212-224 */
+        if (o->sp_variant == 1) anderson_ls(o, broyden_k); else anderson(o, broyden_k);
         tau = 1.;
         int backtrack_count = 0, loop = 1;
         /* K0 is unreachable: should_perform_k0 returns `... && false` (sp.jl:80) */
@@ -878,6 +954,7 @@ static void run_sp(orc *o, int max_iter, double tol, int verbose, double gamma, 
                 continue;
             }
             /* perform_linesearch!(tau, beta): the returned tau*beta is discarded (sp.jl:439) -> tau stays 1 */
+            if (o->sp_variant == 1) tau *= beta;                                                     /* corrected variant: it is kept */
             backtrack_count += 1;
         }
         if (loop) {                                                                                  /* :443-446 */

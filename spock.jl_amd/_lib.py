@@ -32,7 +32,8 @@ class Problem(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("algorithm", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("split_stage", C.c_int32),
-                ("L_norm", C.c_double), ("max_iter", C.c_int32), ("graph_iters", C.c_int32), ("batch_layout", C.c_int32)]
+                ("L_norm", C.c_double), ("max_iter", C.c_int32), ("graph_iters", C.c_int32), ("batch_layout", C.c_int32),
+                ("sp_variant", C.c_int32), ("sp_max_backtrack", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Result(C.Structure):

@@ -41,6 +41,7 @@ struct spock_handle_s {
     // device memory
     real *d_mats = nullptr, *d_z[3] = {nullptr, nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}, *d_v2x = nullptr;
     bool lat_regime = false;   // few workgroups in flight (register-resident sweep): SUB_B runs as MODE_SUB_B_LAT
+    int sp_variant = 0, sp_max_bt = 8;   // SP: 0 = the reference's run_sp! as it stands, 1 = corrected Anderson + working line search
     bool sp_fused = false;   // SP: the inner products with the residuals come out of phase B instead of out of LOP kernels
     bool fused = false;   // CP iteration = CROWN + SUB_BA (after one SUB_A) instead of SUB_A + CROWN + SUB_B
     real *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_x0 = nullptr, *d_xlbuf = nullptr;
@@ -352,6 +353,7 @@ SpArgs make_sp_args(spock_handle_s *h, int op) {
     a.n_partF = sp_flat_blocks(a.nr); a.n_partL = sp_lop_blocks(dm);
     a.batch = h->batch; a.op = op;
     a.partG = h->d_partials; a.n_partG = dm.t0 > 0 ? dm.nsub + 1 : 1; a.fused_lop = h->sp_fused ? 1 : 0;
+    a.variant = h->sp_variant; a.tau = 1.; a.trial = 0; a.last_trial = 1;
     return a;
 }
 
@@ -372,6 +374,25 @@ int launch_sp_T(spock_handle_s *h, real *in, real *out, int sp_mode = 0, const r
 
 int launch_sp_iteration(spock_handle_s *h) {
     int e = launch_sp_T(h, h->s_vec[SV_Z], h->s_vec[SV_ZB], 1);
+    if (h->sp_variant == 1) {
+        // corrected variant (spock_sp.hpp: sp_ctl_a_ls, sp_ctl_trial): T(Z), FLAT1, CTL_A (normal equations), FLAT3, then per
+        // line-search candidate j = 0 .. max_backtrack: [W = Z + beta^j D], T(W), decision; FLAT5, CTL_E.  The kernels of the
+        // candidates behind the accepted one exit at once (done == 3).
+        const int seq1[] = {SP_FLAT1, SP_CTL_A, SP_FLAT3};
+        for (int op : seq1) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
+        double tau = 1.;
+        for (int j = 0; j <= h->sp_max_bt && !e; ++j, tau *= 0.5) {
+            SpArgs a = make_sp_args(h, SP_FLATW);
+            a.tau = tau; a.trial = j; a.last_trial = (j == h->sp_max_bt) ? 1 : 0;
+            if (j > 0) e = launch_sp(a, h->stream);
+            if (!e) e = launch_sp_T(h, h->s_vec[SV_W], h->s_vec[SV_WB], 2, h->s_vec[SV_D]);
+            a.op = SP_CTL_CD;
+            if (!e) e = launch_sp(a, h->stream);
+        }
+        const int seq2[] = {SP_FLAT5, SP_CTL_E};
+        for (int op : seq2) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
+        return e;
+    }
     if (h->sp_fused) {   // every inner product and residual norm comes out of phase B of the two T evaluations: 13 launches
         const int seq1[] = {SP_FLAT1, SP_CTL_A, SP_FLAT2, SP_CTL_B, SP_FLAT3};
         for (int op : seq1) if (!e) e = launch_sp(make_sp_args(h, op), h->stream);
@@ -532,9 +553,13 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     h->batch = o && o->batch > 0 ? o->batch : 1;
     h->L_norm = (o && std::isfinite(o->L_norm) && o->L_norm > 0.) ? o->L_norm : (alg == SPOCK_ALG_CP ? 10. : 3.28);  // cpock.jl:63, models/spock.jl:64
     h->max_iter = o && o->max_iter > 0 ? o->max_iter : (alg == SPOCK_ALG_CP ? 5000 : 1000);                          // cp.jl:190, sp.jl:360
+    h->sp_variant = (o && alg == SPOCK_ALG_SP) ? o->sp_variant : 0;
+    if (h->sp_variant < 0 || h->sp_variant > 1) { delete h; return fail(SPOCK_ERR_BAD_ARG, "sp_variant must be 0 (as the reference) or 1 (corrected)"); }
+    h->sp_max_bt = (o && o->sp_max_backtrack > 0) ? o->sp_max_backtrack : 8;                                        // sp.jl:371
+    if (h->sp_max_bt > 16) { delete h; return fail(SPOCK_ERR_BAD_ARG, "sp_max_backtrack must be at most 16"); }
     int gi = o ? o->graph_iters : 0;
     if (const char *e = std::getenv("SPOCK_AMD_GRAPH_ITERS")) gi = std::atoi(e);
-    if (gi == 0) gi = (alg == SPOCK_ALG_SP) ? 8 : 32;
+    if (gi == 0) gi = (alg == SPOCK_ALG_SP) ? (h->sp_variant == 1 ? 2 : 8) : 32;
     {   // negative = eager launches of |gi| iterations per poll.  Either way every repetition starts at buffer slot 0, so
         // |gi| is a multiple of 6 for CP (z rotates through three buffers, v through two) and even for SP
         const int sgn = gi < 0 ? -1 : 1;

@@ -172,10 +172,16 @@ struct SpArgs {
     // per-workgroup partial sums in partG[instance][n_partG][kPartialStride] (slots 4, 5, 6) instead of out of LOP kernels
     const double *partG;
     int n_partG, fused_lop;
+    // corrected variant (spock_options_t.sp_variant = 1): least-squares Anderson, working line search (spock_sp.hpp)
+    int variant;
+    int trial, last_trial;     // line search: index of the candidate this launch belongs to, 1 if no further candidate follows
+    double tau;                // its step: beta^trial
 };
 
 enum SpOp { SP_FLAT1 = 1, SP_FLAT2, SP_FLAT3, SP_FLAT4, SP_FLAT5, SP_LOP_R, SP_LOP_RT, SP_LOP_DP,
-            SP_CTL_A, SP_CTL_B, SP_CTL_C, SP_CTL_D, SP_CTL_CD };
+            SP_CTL_A, SP_CTL_B, SP_CTL_C, SP_CTL_D, SP_CTL_CD,
+            SP_FLATW = 20,    // corrected variant: the next line-search candidate W = Z + tau D
+            SP_CTL_E = 21 };  // corrected variant: end of an iteration, instances parked by an accepted candidate (done == 3) run on
 
 // MODE_SUB_B_SP / MODE_FULL_SP: SUB_B / FULL whose phase B also accumulates the SP driver's inner products (KArgs::sp_mode);
 // separate kernels so that the CP kernels do not carry that code and its registers

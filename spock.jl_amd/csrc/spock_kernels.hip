@@ -227,17 +227,17 @@ __global__ void __launch_bounds__(kFlatThreads) spock_sp_flat_kernel(const SpArg
     const int inst = blockIdx.y;
     const int done = a.ctl[inst].done;
     if (done == 1 || (done && a.op != SP_FLAT5)) return;   // done == 2: the state update of the final iteration still runs
-    __shared__ double red[6 * 16];
+    __shared__ double red[9 * 16];
     const SpCtl c = a.sp[inst];
-    double sums[6] = {0., 0., 0., 0., 0., 0.};
+    double sums[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
     const long stride = (long)gridDim.x * kFlatThreads;
     for (long e = (long)blockIdx.x * kFlatThreads + threadIdx.x; e < a.nr; e += stride) sp_flat_elem(a, c, inst, e, sums);
     if (a.op == SP_FLAT1 || a.op == SP_FLAT2) {
-        block_reduce<6, false>(sums, red);
+        block_reduce<9, false>(sums, red);
         if (threadIdx.x == 0) {
             double *dst = a.partF + ((long)inst * a.n_partF + blockIdx.x) * kSpSums;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) dst[k] = sums[k];
+            for (int k = 0; k < 9; ++k) dst[k] = sums[k];
         }
     }
 }
@@ -282,15 +282,17 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
     Ctl &ctl = a.ctl[inst];
     if (ctl.done) {
         if (a.op == SP_CTL_A && ctl.done == 2 && threadIdx.x == 0) ctl.done = 1;   // the final state update has run
+        if (a.op == SP_CTL_E && ctl.done == 3 && threadIdx.x == 0) ctl.done = 0;   // corrected variant: parked by an accepted candidate
         return;
     }
-    __shared__ double red[12 * 16];
+    if (a.op == SP_CTL_E) return;
+    __shared__ double red[15 * 16];
     SpCtl &c = a.sp[inst];
     const double *pf = a.partF + (long)inst * a.n_partF * kSpSums, *pl = a.partL + (long)inst * a.n_partL * kSpSums;
-    double f[6] = {0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
+    double f[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
     if (a.op == SP_CTL_A || a.op == SP_CTL_B)
         for (int r = threadIdx.x; r < a.n_partF; r += kCtlThreads)
-            for (int k = 0; k < 6; ++k) f[k] += pf[(long)r * kSpSums + k];
+            for (int k = 0; k < 9; ++k) f[k] += pf[(long)r * kSpSums + k];
     double g2[2] = {0., 0.};
     if ((a.op == SP_CTL_A || a.op == SP_CTL_C || a.op == SP_CTL_CD) && a.fused_lop) {
         const double *pg = a.partG + (long)inst * a.n_partG * kPartialStride;
@@ -307,34 +309,36 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
         for (int r = threadIdx.x; r < a.n_partL; r += kCtlThreads) {
             m[0] = spk_max_nan(m[0], pl[(long)r * kSpSums + 2]); m[1] = spk_max_nan(m[1], pl[(long)r * kSpSums + 3]);
         }
-    {   // one pass for all twelve values (eight sums, four maxima): fixed shuffle tree per wave, then the waves in order
-        double val[12] = {f[0], f[1], f[2], f[3], f[4], f[5], l[0], l[1], m[0], m[1], g2[0], g2[1]};
+    {   // one pass for all fifteen values (eleven sums, four maxima): fixed shuffle tree per wave, then the waves in order
+        double val[15] = {f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], l[0], l[1], m[0], m[1], g2[0], g2[1]};
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (kCtlThreads + 63) >> 6;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < 15; ++k) {
             double x = val[k];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const double o = __shfl_down(x, off, 64);
-                x = (k >= 8) ? spk_max_nan(x, o) : x + o;
+                x = (k >= 11) ? spk_max_nan(x, o) : x + o;
             }
             if (lane == 0) red[k * 16 + wave] = x;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {
+            for (int k = 0; k < 15; ++k) {
                 double x = red[k * 16];
-                for (int w = 1; w < nw; ++w) x = (k >= 8) ? spk_max_nan(x, red[k * 16 + w]) : x + red[k * 16 + w];
+                for (int w = 1; w < nw; ++w) x = (k >= 11) ? spk_max_nan(x, red[k * 16 + w]) : x + red[k * 16 + w];
                 val[k] = x;
             }
-            for (int k = 0; k < 6; ++k) f[k] = val[k];
-            l[0] = val[6]; l[1] = val[7]; m[0] = val[8]; m[1] = val[9]; g2[0] = val[10]; g2[1] = val[11];
+            for (int k = 0; k < 9; ++k) f[k] = val[k];
+            l[0] = val[9]; l[1] = val[10]; m[0] = val[11]; m[1] = val[12]; g2[0] = val[13]; g2[1] = val[14];
         }
     }
     if (threadIdx.x == 0) {
         double *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
-        if (a.op == SP_CTL_CD) sp_ctl_cd(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], hist, a.hist_cap);
+        if (a.op == SP_CTL_CD && a.variant == 1) sp_ctl_trial(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], a.tau, a.trial, a.last_trial, hist, a.hist_cap);
+        else if (a.op == SP_CTL_CD) sp_ctl_cd(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], hist, a.hist_cap);
+        else if (a.op == SP_CTL_A && a.variant == 1) sp_ctl_a_ls(c, f, l[0], m[0], m[1]);
         else if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0], m[0], m[1]);
         else if (a.op == SP_CTL_B) sp_ctl_b(c, f);
         else if (a.op == SP_CTL_C) sp_ctl_c(c, ctl, l[0], l[1]);
@@ -379,10 +383,10 @@ int launch_sp(const SpArgs &a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const Dims &dm = a.dm;
     switch (a.op) {
-        case SP_FLAT1: case SP_FLAT2: case SP_FLAT3: case SP_FLAT4: case SP_FLAT5:
+        case SP_FLAT1: case SP_FLAT2: case SP_FLAT3: case SP_FLAT4: case SP_FLAT5: case SP_FLATW:
             hipLaunchKernelGGL(spock_sp_flat_kernel, dim3(a.n_partF, a.batch), dim3(kFlatThreads), 0, st, a);
             return (int)hipGetLastError();
-        case SP_CTL_A: case SP_CTL_B: case SP_CTL_C: case SP_CTL_D: case SP_CTL_CD:
+        case SP_CTL_A: case SP_CTL_B: case SP_CTL_C: case SP_CTL_D: case SP_CTL_CD: case SP_CTL_E:
             hipLaunchKernelGGL(spock_sp_ctl_kernel, dim3(1, a.batch), dim3(kCtlThreads), 0, st, a);
             return (int)hipGetLastError();
         default: break;

@@ -51,7 +51,11 @@ SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, dou
             a.ZOLD[o] = z;
             const real b = q2[e], cc = q3[e];
             sums[0] += dr * dr; sums[1] += b * dr; sums[2] += cc * dr; sums[3] += b * b; sums[4] += cc * cc; sums[5] += b * cc;
+            sums[6] += dr * r; sums[7] += b * r; sums[8] += cc * r;      // MR'r: right-hand side of the corrected variant's normal equations
         } break;
+        case SP_FLATW:                                                   // corrected variant: candidate with the shortened step
+            a.W[o] = a.Z[o] + (real)a.tau * a.D[o];
+            break;
         case SP_FLAT2: {
             const real v = q1[e] - c.r2 * q2[e] - c.r3 * q3[e];   // anderson.jl:88
             q1[e] = v;
@@ -204,6 +208,44 @@ SPK_DEV void sp_ctl_a(SpCtl &c, const double *gram, double pr, double xi1 = 0., 
     if (c.k >= 2) { c.r2 = gram[1] / sqrt(gram[3]); R[0 + 1 * 3] = c.r2; }                       // anderson.jl:77-88, j = 2
     if (c.k >= 3) { c.r3 = (gram[2] - c.r2 * gram[5]) / sqrt(gram[4]); R[0 + 2 * 3] = c.r3; }    // j = 3
 }
+// Corrected variant (no reference counterpart; oracle: anderson_ls): gamma = argmin |r - MR gamma| over the min(k, 3) columns
+// present, by the normal equations with the Gram sums of FLAT1 (the column buffers then hold the raw delta_r columns: FLAT2 /
+// CTL_B are not launched).  A column whose Cholesky pivot falls below 1e-14 of its diagonal entry is dropped.
+SPK_DEV void sp_ctl_a_ls(SpCtl &c, const double *f, double pr, double xi1, double xi2) {
+    c.xi_fb[0] = xi1; c.xi_fb[1] = xi2;
+    c.rnorm = sqrt(pr);
+    c.k += 1;
+    const int m = c.k < 3 ? c.k : 3;
+    const double G[9] = {f[0], f[1], f[2], f[1], f[3], f[5], f[2], f[5], f[4]}, rhs[3] = {f[6], f[7], f[8]};
+    double L[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, y[3] = {0., 0., 0.}, g[3] = {0., 0., 0.};
+    bool valid[3] = {false, false, false};
+    for (int j = 0; j < m; ++j) {
+        double s = G[j + 3 * j];
+        for (int k = 0; k < j; ++k) if (valid[k]) s -= L[j + 3 * k] * L[j + 3 * k];
+        if (!(s > 1e-14 * G[j + 3 * j])) continue;
+        valid[j] = true;
+        L[j + 3 * j] = sqrt(s);
+        for (int i = j + 1; i < m; ++i) {
+            double t = G[i + 3 * j];
+            for (int k = 0; k < j; ++k) if (valid[k]) t -= L[i + 3 * k] * L[j + 3 * k];
+            L[i + 3 * j] = t / L[j + 3 * j];
+        }
+    }
+    for (int j = 0; j < m; ++j) {
+        if (!valid[j]) continue;
+        double t = rhs[j];
+        for (int k = 0; k < j; ++k) if (valid[k]) t -= L[j + 3 * k] * y[k];
+        y[j] = t / L[j + 3 * j];
+    }
+    for (int j = 2; j >= 0; --j) {
+        if (j >= m || !valid[j]) continue;
+        double t = y[j];
+        for (int k = j + 1; k < m; ++k) if (valid[k]) t -= L[k + 3 * j] * g[k];
+        g[j] = t / L[j + 3 * j];
+    }
+    c.g[0] = g[0]; c.g[1] = g[1]; c.g[2] = g[2];
+    c.rho = 1.; c.r2 = 0.; c.r3 = 0.;     // FLAT3's normalisation of the newest column becomes the identity
+}
 SPK_DEV void sp_ctl_b(SpCtl &c, const double *s4) {
     c.rho = sqrt(s4[0]);                                             // anderson.jl:70-75 / :93-99
     c.R[0] = c.rho;
@@ -273,6 +315,38 @@ SPK_DEV void sp_ctl_cd(SpCtl &c, Ctl &ctl, double s_rt, double s_rtd, double xw1
     else if (c.accept == 2) { const double f = fabs(c.coef); x1 = f * xw1; x2 = f * xw2; }
     else { x1 = c.xi_fb[0]; x2 = c.xi_fb[1]; }
     sp_ctl_d(c, ctl, x1, x2, hist, hist_cap, 2);
+}
+
+// Corrected variant, candidate `trial` of the line search with step tau = beta^trial (run_sp!'s loop sp.jl:411-441 with the
+// result of perform_linesearch! kept).  An accepted candidate (or the last rejected one: plain CP step) closes the iteration --
+// termination test, history, counters as in CTL_CD -- and parks the instance (done = 3) so that the kernels of the remaining
+// candidates exit at once; SP_CTL_E at the end of the iteration re-opens it.
+SPK_DEV void sp_ctl_trial(SpCtl &c, Ctl &ctl, double s_rt, double s_rtd, double xw1, double xw2, double ld1, double ld2,
+                          double tau, int trial, int last, double *hist, int hist_cap) {
+    const double c1 = 0.99, q = 0.99, sigma_k2 = 0.1, lambda_sp = 1.;
+    c.rtilde = sqrt(s_rt);
+    c.accept = 0; c.coef = 0.; c.backtrack = trial;
+    if (c.rnorm <= c.r_safe && c.rtilde <= c1 * c.rnorm) {           // K1
+        c.accept = 1;
+        c.r_safe = c.rtilde + pow(q, (double)ctl.iter);
+    } else {
+        const double rho = s_rt - tau * s_rtd;                       // <rt, P (rt - tau d)>
+        c.rho_dot = rho;
+        if (rho >= sigma_k2 * c.rnorm * c.rtilde) {                  // K2
+            c.accept = 2;
+            c.coef = lambda_sp * (rho / (c.rtilde * c.rtilde));
+        }
+    }
+    if (c.accept == 0) {
+        if (!last) return;                                           // rejected: the next candidate follows
+        c.backtrack = trial + 1;                                     // all candidates rejected: plain CP step
+    }
+    double x1, x2;
+    if (c.accept == 1) { x1 = tau * ld1; x2 = tau * ld2; }           // dp = tau d
+    else if (c.accept == 2) { const double f = fabs(c.coef); x1 = f * xw1; x2 = f * xw2; }
+    else { x1 = c.xi_fb[0]; x2 = c.xi_fb[1]; }
+    sp_ctl_d(c, ctl, x1, x2, hist, hist_cap, 2);
+    if (!ctl.done && !last) ctl.done = 3;
 }
 
 }  // namespace spock

@@ -34,6 +34,7 @@ end
 struct SpockOptionsC           # spock_options_t
     algorithm::Cint; device::Cint; batch::Cint; split_stage::Cint
     L_norm::Cdouble; max_iter::Cint; graph_iters::Cint; batch_layout::Cint
+    sp_variant::Cint; sp_max_backtrack::Cint; reserved_::Cint
 end
 
 struct SpockResultC            # spock_result_t
@@ -101,7 +102,7 @@ function build_model(scen_tree::AbstractScenarioTree, cost::AbstractCost, dynami
                           nQ, nR, nQN, pointer(Q), pointer(R), pointer(QN), pointer(E), pointer(F), pointer(b),
                           length(kinds), pointer(kinds), pointer(dims),
                           constraints.x_min, constraints.x_max, constraints.u_min, constraints.u_max)
-        o = SpockOptionsC(Int(solver_options.algorithm), gpu.device, gpu.batch, 0, gpu.L_norm, 0, 0, 0)
+        o = SpockOptionsC(Int(solver_options.algorithm), gpu.device, gpu.batch, 0, gpu.L_norm, 0, 0, 0, 0, 0, 0)   # sp_variant 0: as the reference
         gpu_check(ccall((:spock_create, libspock_amd), Cint, (Ref{SpockProblemC}, Ref{SpockOptionsC}, Ref{Ptr{Cvoid}}), p, o, h))
     end
     sz = Ref{SpockSizesC}()

@@ -96,7 +96,8 @@ class Model:
 
     def __init__(self, flat: FlatProblem, options: SolverOptions, batch: int = 1, device: int = 0,
                  L_norm: float | str | None = None, max_iter: int = 0, split_stage: int = 0, graph_iters: int = 0,
-                 lib_path: str | None = None, layout: str | int | None = None, dtype: str = "f64"):
+                 lib_path: str | None = None, layout: str | int | None = None, dtype: str = "f64", sp_variant: int = 0,
+                 sp_max_backtrack: int = 0):
         if dtype not in ("f64", "f32"):
             raise ValueError("dtype must be 'f64' or 'f32'")
         self._lib = _lib.load_library(lib_path or (_lib.F32_LIB if dtype == "f32" else None))
@@ -111,7 +112,7 @@ class Model:
         lay = {None: 0, "auto": 0, "instance": 1, "instance-major": 1, "interleaved": 2, "element-major": 2}.get(layout, layout)
         op = _lib.Options(int(options.algorithm), int(device), self.batch, int(split_stage),
                           float("nan") if L_norm is None else (-1.0 if L_norm == "auto" else float(L_norm)), int(max_iter), int(graph_iters),
-                          int(lay))
+                          int(lay), int(sp_variant), int(sp_max_backtrack), 0)
         h = C.c_void_p()
         _lib.check(self._lib, self._lib.spock_create(C.byref(pr), C.byref(op), C.byref(h)))
         self._h = h

@@ -289,16 +289,16 @@ static int emu_lop(const SpArgs &a) {
 
 int launch_sp(const SpArgs &a, void *) {
     const Dims &dm = a.dm;
-    if (a.op >= SP_FLAT1 && a.op <= SP_FLAT5) {
+    if ((a.op >= SP_FLAT1 && a.op <= SP_FLAT5) || a.op == SP_FLATW) {
         for (int inst = 0; inst < a.batch; ++inst) {
             const int done = a.ctl[inst].done;
             if (done == 1 || (done && a.op != SP_FLAT5)) continue;   // done == 2: the state update of the final iteration still runs
             const SpCtl c = a.sp[inst];
             for (int blk = 0; blk < a.n_partF; ++blk) {
-                real sums[6] = {0., 0., 0., 0., 0., 0.};
+                real sums[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
                 for (long e = blk; e < a.nr; e += a.n_partF) sp_flat_elem(a, c, inst, e, sums);
                 real *dst = a.partF + ((long)inst * a.n_partF + blk) * kSpSums;
-                if (a.op == SP_FLAT1 || a.op == SP_FLAT2) for (int k = 0; k < 6; ++k) dst[k] = sums[k];
+                if (a.op == SP_FLAT1 || a.op == SP_FLAT2) for (int k = 0; k < 9; ++k) dst[k] = sums[k];
             }
         }
         return 0;
@@ -306,11 +306,12 @@ int launch_sp(const SpArgs &a, void *) {
     if (a.op >= SP_CTL_A) {
         for (int inst = 0; inst < a.batch; ++inst) {
             Ctl &ctl = a.ctl[inst];
-            if (ctl.done) { if (a.op == SP_CTL_A && ctl.done == 2) ctl.done = 1; continue; }
+            if (ctl.done) { if (a.op == SP_CTL_A && ctl.done == 2) ctl.done = 1; if (a.op == SP_CTL_E && ctl.done == 3) ctl.done = 0; continue; }
+            if (a.op == SP_CTL_E) continue;
             SpCtl &c = a.sp[inst];
             const real *pf = a.partF + (long)inst * a.n_partF * kSpSums, *pl = a.partL + (long)inst * a.n_partL * kSpSums;
-            real f[6] = {0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
-            for (int r = 0; r < a.n_partF; ++r) for (int k = 0; k < 6; ++k) f[k] += pf[(long)r * kSpSums + k];
+            real f[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, l[2] = {0., 0.}, m[2] = {0., 0.};
+            for (int r = 0; r < a.n_partF; ++r) for (int k = 0; k < 9; ++k) f[k] += pf[(long)r * kSpSums + k];
             for (int r = 0; r < a.n_partL; ++r) {
                 l[0] += pl[(long)r * kSpSums]; l[1] += pl[(long)r * kSpSums + 1];
                 m[0] = spk_max_nan(m[0], pl[(long)r * kSpSums + 2]); m[1] = spk_max_nan(m[1], pl[(long)r * kSpSums + 3]);
@@ -327,7 +328,9 @@ int launch_sp(const SpArgs &a, void *) {
                 }
             }
             real *hist = a.hist ? a.hist + (long)inst * a.hist_cap * kHistStride : nullptr;
-            if (a.op == SP_CTL_CD) sp_ctl_cd(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], hist, a.hist_cap);
+            if (a.op == SP_CTL_CD && a.variant == 1) sp_ctl_trial(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], a.tau, a.trial, a.last_trial, hist, a.hist_cap);
+            else if (a.op == SP_CTL_CD) sp_ctl_cd(c, ctl, l[0], l[1], m[0], m[1], g2[0], g2[1], hist, a.hist_cap);
+            else if (a.op == SP_CTL_A && a.variant == 1) sp_ctl_a_ls(c, f, l[0], m[0], m[1]);
             else if (a.op == SP_CTL_A) sp_ctl_a(c, f, l[0], m[0], m[1]);
             else if (a.op == SP_CTL_B) sp_ctl_b(c, f);
             else if (a.op == SP_CTL_C) sp_ctl_c(c, ctl, l[0], l[1]);

@@ -448,6 +448,36 @@ def test_unsupported_inputs(S, emu):
         S.build_model(bad, cost, dyn, rms, con, lib_path=emu)
 
 
+@pytest.mark.parametrize("N,nu,x0s,mb,cap,tol", [(5, 5, 0.1, 0, 400, 1e-3), (7, 2, 0.3, 2, 70, 1e-4), (5, 2, 1.0, 2, 80, 1e-4)])
+def test_emulated_sp_corrected_variant(S, O, emu, N, nu, x0s, mb, cap, tol):
+    """spock_options_t.sp_variant = 1 (least-squares Anderson, a line search that shortens the step; no reference counterpart)
+    against the oracle's statement of the same algorithm: a converging solve, and two harder problems whose line search rejects
+    candidates at every depth down to the plain CP step.  Two instances per handle: a candidate accepted by one instance parks
+    only that instance for the rest of the iteration."""
+    specs = S.get_server_heat_specs(N, 5, 2, nu=nu)
+    flat = S.flatten_problem(*specs)
+    x0 = np.array([np.full(5, x0s), np.full(5, 0.7 * x0s)])
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, batch=2, max_iter=cap, sp_variant=1, sp_max_backtrack=mb)
+    rs = S.solve_model(m, x0, tol=tol, verbose=S.LOG)
+    seen = set()
+    for b in range(2):
+        o = O.Oracle(flat, O.SP, sp_variant=1, sp_max_backtrack=mb)
+        ro = o.solve(x0[b], tol=tol, verbose=O.LOG, max_iter=cap, history=cap + 2)
+        h = m.history(b)
+        n = min(len(h["xi"]), len(ro["hist_xi"]), 40)      # (rounding differences grow along an SP trajectory: DESIGN.md section 4)
+        assert np.array_equal(h["backtrack"][:n], ro["hist_backtrack"][:n])
+        assert np.max(np.abs(h["xi"][:n] - ro["hist_xi"][:n]) / ro["hist_xi"][:n]) <= 1e-6
+        seen |= set(int(x) for x in h["backtrack"])
+        if ro["status"] == 0:
+            assert (rs[b]["iterations"], rs[b]["status"]) == (ro["iterations"], 0)
+            assert relerr(m.solver_state.z[b], o.z) <= 1e-6
+    if mb:
+        assert {0, 1, mb + 1} <= seen        # accepted at once, after one shortening, and every candidate rejected
+    m.close()
+    with pytest.raises(S.SpockError):
+        S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, sp_variant=2)
+
+
 # ---- element-major ("interleaved") batched regime: one lane per instance, one wave per tree node (spock_igroup.hpp) -----------
 @pytest.mark.parametrize("N,nu,B,kw", [(5, 5, 3, {}), (7, 2, 3, {}), (7, 5, 66, {}), (8, 2, 4, {"split_stage": 5}),
                                        (10, 5, 2, {"split_stage": 8}), (8, 2, 70, {"split_stage": 2}),

@@ -401,6 +401,33 @@ def test_sp_batch_matches_single_and_lop_sequence(S, O, monkeypatch):
     assert np.array_equal(hb[0]["backtrack"][:n], ro["hist_backtrack"][:n])
 
 
+@pytest.mark.parametrize("N,nu,x0s,mb,cap,tol", [(7, 5, 0.1, 0, 400, 1e-3), (7, 2, 0.3, 2, 70, 1e-4), (5, 2, 1.0, 2, 80, 1e-4)])
+def test_sp_corrected_variant(S, O, N, nu, x0s, mb, cap, tol):
+    """spock_options_t.sp_variant = 1 (least-squares Anderson + a line search that shortens the step; no reference counterpart)
+    on the GPU against the oracle's statement of the same algorithm: identical backtrack counts, residual log of the first 40
+    iterations <= 1e-6, a converging solve with the same iteration count.  Two instances per handle."""
+    specs = S.get_server_heat_specs(N, 5, 2, nu=nu)
+    flat = S.flatten_problem(*specs)
+    x0 = np.array([np.full(5, x0s), np.full(5, 0.7 * x0s)])
+    m = S.build_model(*specs, S.SolverOptions(S.SP, None), batch=2, max_iter=cap, sp_variant=1, sp_max_backtrack=mb)
+    rs = S.solve_model(m, x0, tol=tol, verbose=S.LOG)
+    seen = set()
+    for b in range(2):
+        o = O.Oracle(flat, O.SP, sp_variant=1, sp_max_backtrack=mb)
+        ro = o.solve(x0[b], tol=tol, verbose=O.LOG, max_iter=cap, history=cap + 2)
+        h = m.history(b)
+        n = min(len(h["xi"]), len(ro["hist_xi"]), 40)
+        assert np.array_equal(h["backtrack"][:n], ro["hist_backtrack"][:n])
+        assert np.max(np.abs(h["xi"][:n] - ro["hist_xi"][:n]) / ro["hist_xi"][:n]) <= 1e-6
+        seen |= set(int(x) for x in h["backtrack"])
+        if ro["status"] == 0:
+            assert (rs[b]["iterations"], rs[b]["status"]) == (ro["iterations"], 0)
+            assert relerr(m.solver_state.z[b], o.z) <= 1e-6
+    if mb:
+        assert {0, 1, mb + 1} <= seen
+    m.close()
+
+
 # ---- element-major ("interleaved") batched regime (spock_igroup.hpp): one lane per instance, one wave per tree node -----------
 @pytest.mark.parametrize("N,nu,B,kw", [(7, 5, 70, {}), (8, 2, 64, {"split_stage": 5}), (10, 5, 130, {}), (9, 2, 70, {"split_stage": 2}),
                                        (10, 5, 130, {"stream": "0"})])
