@@ -179,6 +179,13 @@ int spock_op_T(spock_handle_t h, const double *x0, const double *z, const double
  * 3 ABK, 4 kernel projector, 5 sqrtQ, 6 sqrtR, 7 sqrtQN.  *len receives the element count. */
 int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_t cap, int32_t *len);
 
+/* The dynamics-dependent part of the build step ON THE DEVICE: ricatti_offline (src/model_dynamics/implicit_l.jl:46-97: P, K,
+ * Rtilde^-1, A + B K per stage) and the composite matrices of the S1 sweep, recomputed in the handle's matrix pool for new dynamics
+ * of the same shape -- A: [d][nx*nx], B: [d][nx*nu], host pointers.  Costs, risk measures, constraints, state and step sizes are
+ * kept.  The reference rebuilds the whole model (build_model) when the dynamics change; this replaces that for e.g. a model
+ * re-linearised between the steps of a closed loop.  SPOCK_ERR_BUILD when Rtilde is not positive definite. */
+int spock_update_dynamics(spock_handle_t h, const double *A, const double *B);
+
 /* L_norm in use (step sizes default to 0.99/sqrt(L_norm), cp.jl:198-201) and the closed-form ||L||^2 of this problem */
 int spock_L_norm(spock_handle_t h, double *in_use, double *closed_form);
 /* device time of the last solve divided by its iteration count, and that count */

@@ -71,6 +71,7 @@ SYMBOLS = {
     "spock_L_norm": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_D)]),
     "spock_get_timing": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_I)]),
     "spock_profile_kernels": (C.c_int, [_P, _I, _P, _P]),
+    "spock_update_dynamics": (C.c_int, [_P, _P, _P]),
     "spock_profile_sequence": (C.c_int, [_P, _I, _P, _P, _P, _I, _P]),
     "spock_debug_stamps": (C.c_int, [_P, _P]),
     "spock_last_error": (C.c_char_p, []),

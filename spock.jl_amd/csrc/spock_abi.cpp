@@ -41,6 +41,7 @@ struct spock_handle_s {
     // device memory
     real *d_mats = nullptr, *d_z[3] = {nullptr, nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}, *d_v2x = nullptr;
     bool lat_regime = false;   // few workgroups in flight (register-resident sweep): SUB_B runs as MODE_SUB_B_LAT
+    bool dyn_on_device = false;   // spock_update_dynamics has run: P, K, Rtilde^-1, ABK of spock_get_build_product come from the device pool
     int sp_variant = 0, sp_max_bt = 8;   // SP: 0 = the reference's run_sp! as it stands, 1 = corrected Anderson + working line search
     bool sp_fused = false;   // SP: the inner products with the residuals come out of phase B instead of out of LOP kernels
     bool fused = false;   // CP iteration = CROWN + SUB_BA (after one SUB_A) instead of SUB_A + CROWN + SUB_B
@@ -1001,7 +1002,50 @@ int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_
         default: return fail(SPOCK_ERR_BAD_ARG, "unknown build product");
     }
     if (len) *len = (int32_t)src->size();
+    if (out && h->dyn_on_device && which <= 3) {   // rebuilt on the device since: read the pool
+        const Dims &dm = h->bp.dm;
+        const int off = which == 0 ? dm.mP : which == 1 ? dm.mK : which == 2 ? dm.mRinv : dm.mABK;
+        const size_t k = src->size() < (size_t)cap ? src->size() : (size_t)cap;
+        DeviceGuard guard(h->device);
+        RTCHECK(down(h, out, h->d_mats + off, k));
+        RTCHECK(rt::sync(h->stream));
+        return SPOCK_OK;
+    }
     if (out) { const size_t k = src->size() < (size_t)cap ? src->size() : (size_t)cap; std::memcpy(out, src->data(), k * sizeof(double)); }
+    return SPOCK_OK;
+}
+
+// The dynamics-dependent part of the build step on the device (spock_build.hpp): ricatti_offline (implicit_l.jl:46-97) and the
+// composite sweep matrices for new A_w, B_w of the same shape, written into the handle's matrix pool.
+int spock_update_dynamics(spock_handle_t h, const double *A, const double *B) {
+    if (!h || !A || !B) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    DeviceGuard guard(h->device);
+    const Dims &dm = h->bp.dm;
+    const size_t na = (size_t)dm.d * dm.nx * dm.nx, nb = (size_t)dm.d * dm.nx * dm.nu;
+    for (size_t k = 0; k < na; ++k) if (!std::isfinite(A[k])) return fail(SPOCK_ERR_BAD_ARG, "A must be finite");
+    for (size_t k = 0; k < nb; ++k) if (!std::isfinite(B[k])) return fail(SPOCK_ERR_BAD_ARG, "B must be finite");
+    void *dA = nullptr, *dB = nullptr, *dws = nullptr, *dst = nullptr;
+    int e = rt::dmalloc(&dA, na * sizeof(double));
+    if (!e) e = rt::dmalloc(&dB, nb * sizeof(double));
+    if (!e) e = rt::dmalloc(&dws, (size_t)build_ws_doubles(dm) * sizeof(double));
+    if (!e) e = rt::dmalloc(&dst, sizeof(int));
+    int status = 0;
+    if (!e) e = rt::h2d(dA, A, na * sizeof(double), h->stream);
+    if (!e) e = rt::h2d(dB, B, nb * sizeof(double), h->stream);
+    if (!e) {
+        BuildArgs a;
+        a.dm = dm; a.mats = h->d_mats; a.A = (const double *)dA; a.B = (const double *)dB; a.ws = (double *)dws; a.status = (int *)dst;
+        e = launch_build_riccati(a, h->stream);
+    }
+    if (!e) e = rt::d2h(&status, dst, sizeof(int), h->stream);
+    if (!e) e = rt::sync(h->stream);
+    for (void *q : {dA, dB, dws, dst}) if (q) rt::dfree(q);
+    if (e) return fail(SPOCK_ERR_HIP, std::string("spock_update_dynamics: ") + rt::err(e));
+    h->hp.A.assign(A, A + na); h->hp.B.assign(B, B + nb);
+    h->dyn_on_device = true;
+    if (h->graph) { rt::graph_destroy(h->graph); h->graph = nullptr; }        // (the captured launches carry no pool contents, but stay on the safe side)
+    if (h->graph_log) { rt::graph_destroy(h->graph_log); h->graph_log = nullptr; }
+    if (status != 0) return fail(SPOCK_ERR_BUILD, "Rtilde is not positive definite");
     return SPOCK_OK;
 }
 

@@ -262,6 +262,18 @@ int launch_transpose(real *dst, const real *src, long rows, long cols, long ld_s
 // element-major state: column b of z0 / v0 <- column b of the buffer its control block's result_parity names
 int launch_ilv_collect(real *const *z3, real *const *v2, const Ctl *ctl, long nz, long nv, long bp, int batch, void *stream);
 int launch_sp(const SpArgs &a, void *stream);   // a.op selects the kernel (spock_sp.hpp)
+// on-device build step for new dynamics (spock_build.hpp); workspace size in doubles
+struct BuildArgs {
+    Dims dm;
+    real *mats;          // the matrix pool (device)
+    const double *A;     // [d][nx*nx] new dynamics (device)
+    const double *B;     // [d][nx*nu]
+    double *ws;          // workspace, build_ws_doubles(dm) doubles
+    int *status;         // 0 ok, 1 Rtilde not positive definite
+};
+
+int launch_build_riccati(const BuildArgs &a, void *stream);
+inline long build_ws_doubles(const Dims &dm) { return 7L * dm.nx * dm.nx + 6L * dm.nu * dm.nx + 4L * dm.nu * dm.nu + (long)dm.d * dm.nx * dm.nx; }
 int sp_flat_blocks(long nr);                    // workgroups per instance of the flat kernels
 int sp_lop_blocks(const Dims &dm);              // workgroups per instance of the LOP kernels
 

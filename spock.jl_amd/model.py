@@ -186,6 +186,16 @@ class Model:
         _lib.check(self._lib, self._lib.spock_profile_kernels(self._h, int(reps), _ptr(ms), _ptr(n)))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(("sub_a", "crown", "sub_b", "full"))}
 
+    def update_dynamics(self, dynamics):
+        """New dynamics of the same shape: ricatti_offline (implicit_l.jl:46-97) and the sweep matrices are recomputed on the GPU in
+        the model's matrix pool (spock_update_dynamics); costs, risk measures, constraints and the solver state are kept."""
+        from .problem import _stack_colmajor
+        fl = self.problem_definition
+        if len(dynamics.A) != fl.d or len(dynamics.B) != fl.d:
+            raise ValueError("the new dynamics must have the shape of the old ones")
+        A = _stack_colmajor(dynamics.A, fl.nx, fl.nx); B = _stack_colmajor(dynamics.B, fl.nx, fl.nu)
+        _lib.check(self._lib, self._lib.spock_update_dynamics(self._h, _ptr(A), _ptr(B)))
+
     MODE_NAMES = {0: "full", 1: "sub_a", 2: "crown", 3: "sub_b", 5: "sub_ba", 8: "sub_b_lat", 9: "crown_a", 10: "i_up", 11: "i_down",
                   12: "lb", 13: "lba", 14: "la", 15: "la0"}
 

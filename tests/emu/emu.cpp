@@ -17,6 +17,7 @@
 #include "../../spock.jl_amd/csrc/spock_group.hpp"
 #include "../../spock.jl_amd/csrc/spock_igroup.hpp"
 #include "../../spock.jl_amd/csrc/spock_ilevel.hpp"
+#include "../../spock.jl_amd/csrc/spock_build.hpp"
 #include "../../spock.jl_amd/csrc/spock_sp.hpp"
 #include "../../spock.jl_amd/csrc/spock_team_local.hpp"
 #include "../../spock.jl_amd/csrc/spock_rt.hpp"
@@ -187,6 +188,16 @@ static int launch_ivariant(int mode, const KArgs &a_in) {
         case MODE_LA0: run_lblocks<P, MODE_LA0>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, nullptr, nullptr); break;
         default: return 1;
     }
+    return 0;
+}
+
+struct EmuBuildExec {
+    template <class F> void par(int n, F &&f) { for (int i = 0; i < n; ++i) f(i); }
+    template <class F> void one(F &&f) { f(); }
+};
+int launch_build_riccati(const BuildArgs &a, void *) {
+    EmuBuildExec x;
+    build_riccati_body(x, a);
     return 0;
 }
 

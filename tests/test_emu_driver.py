@@ -478,6 +478,38 @@ def test_emulated_sp_corrected_variant(S, O, emu, N, nu, x0s, mb, cap, tol):
         S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, sp_variant=2)
 
 
+def test_emulated_build_step_on_the_device(S, O, emu):
+    """spock_update_dynamics: ricatti_offline (implicit_l.jl:46-97) and the composite sweep matrices recomputed by the device-side
+    build step for new dynamics of the same shape, against a model built from scratch on the host with those dynamics: build
+    products P, K, Rtilde^-1, A + B K to rounding, the same CP iterates, the closed loop advancing with the new A, B."""
+    import dataclasses
+    tree, cost, dyn, rms, con = S.get_server_heat_specs(6, 5, 2)
+    rng = np.random.default_rng(3)
+    dyn2 = dataclasses.replace(dyn, A=[0.9 * a + 0.01 * rng.standard_normal(a.shape) for a in dyn.A],
+                               B=[b + 0.05 * rng.standard_normal(b.shape) for b in dyn.B])
+    x0 = np.array([0.1, -0.1, 0.05, 0.2, 0.3])
+    ref = S.build_model(tree, cost, dyn2, rms, con, lib_path=emu, max_iter=60)
+    m = S.build_model(tree, cost, dyn, rms, con, lib_path=emu, max_iter=60)
+    S.solve_model(m, x0, tol=1e-3); m.reset()          # (a solve with the old dynamics first: captured graphs are dropped)
+    m.update_dynamics(dyn2)
+    for which in (0, 1, 2, 3):      # P, K, Rtilde^-1, A + B K
+        a, b = m.build_product(which), ref.build_product(which)
+        assert a.shape == b.shape and relerr(a, b) <= 1e-12, which
+    r1 = S.solve_model(m, x0, tol=1e-6); r2 = S.solve_model(ref, x0, tol=1e-6)
+    assert r1["iterations"] == r2["iterations"] == 60
+    assert relerr(m.solver_state.z, ref.solver_state.z) <= 1e-10
+    o = O.Oracle(S.flatten_problem(tree, cost, dyn2, rms, con), O.CP); o.solve(x0, tol=1e-6, max_iter=60)
+    assert relerr(m.solver_state.z, o.z) <= 1e-9
+    w = np.array([[0, 1, 1]])
+    m.reset(); ref.reset()
+    xa, ua, _ = S.mpc_simulation(m, x0, w, tol=1e-3); xb, ub, _ = S.mpc_simulation(ref, x0, w, tol=1e-3)
+    assert np.max(np.abs(xa - xb)) <= 1e-10 and np.max(np.abs(ua - ub)) <= 1e-10
+    bad = dataclasses.replace(dyn, A=[np.full_like(a, np.nan) for a in dyn.A])
+    with pytest.raises(S.SpockError):
+        m.update_dynamics(bad)
+    m.close(); ref.close()
+
+
 # ---- element-major ("interleaved") batched regime: one lane per instance, one wave per tree node (spock_igroup.hpp) -----------
 @pytest.mark.parametrize("N,nu,B,kw", [(5, 5, 3, {}), (7, 2, 3, {}), (7, 5, 66, {}), (8, 2, 4, {"split_stage": 5}),
                                        (10, 5, 2, {"split_stage": 8}), (8, 2, 70, {"split_stage": 2}),
@@ -522,6 +554,39 @@ def test_emulated_interleaved_layout_matches_oracle(S, O, emu, monkeypatch, N, n
     assert np.array_equal(m.solver_state.z.reshape(B, -1), Z)     # bitwise repeatable
     m.reset()
     assert not m.solver_state.z.any()
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["shared_dense_costs", "d3_tree", "nx2_nu1", "soc_risk_cone"])
+def test_emulated_interleaved_shapes_and_cost_modes(S, O, emu, name):
+    """The role waves of the level-streaming kernels on the other compile-time shapes and cost modes: shared dense cost roots
+    (CM_SHARED), branching factor 3 (three C_c and three L_c waves per workgroup), nx = 2 / nu = 1, a second-order sub-cone in the
+    risk cone; CP against the oracle in SILENT and LOG mode."""
+    rng = np.random.default_rng(5)
+    if name == "shared_dense_costs":
+        tree, cost, dyn, rms, con = S.get_server_heat_specs(6, 5, 2)
+        a = rng.standard_normal((5, 5)); Q = 0.05 * (a @ a.T) / 5 + 0.05 * np.eye(5)
+        specs = (tree, S.Cost([Q], [np.eye(5) + 0.2 * Q], [Q.copy()]), dyn, rms, con)
+    elif name == "d3_tree":
+        specs = S.get_random_linear_specs(5, 3, 2, d=3)
+    elif name == "nx2_nu1":
+        specs = S.get_random_linear_specs(7, 2, 1)
+    else:
+        tree, cost, dyn, _, con = S.get_server_heat_specs(6, 5, 2)
+        E = np.vstack([0.95 * np.eye(2), -np.eye(2), np.ones((1, 2))]); F = np.zeros((5, 2)); b = np.array([0.3, 0.7, 0, 0, 1.0])
+        specs = (tree, cost, dyn, S.get_uniform_rms_v2(E, F, b, S.ConvexCone([(S.CONE_SOC, 3), (S.CONE_NONNEG, 1), (S.CONE_REALS, 1)]), 2, 6), con)
+    flat = S.flatten_problem(*specs)
+    B, nx = 3, flat.nx
+    x0 = 0.1 * (1 + 0.3 * np.arange(B))[:, None] * np.cos(np.arange(nx))[None, :]
+    m = S.build_model(*specs, lib_path=emu, batch=B, layout="interleaved", max_iter=50, split_stage=2)
+    assert m.sizes.interleaved == 1
+    for verbose, ov in ((S.SILENT, O.SILENT), (S.LOG, O.LOG)):
+        m.reset()
+        rs = S.solve_model(m, x0, tol=1e-4, verbose=verbose)
+        for b in range(B):
+            o = O.Oracle(flat, O.CP); ro = o.solve(x0[b], tol=1e-4, max_iter=50, verbose=ov)
+            assert (rs[b]["iterations"], rs[b]["status"]) == (ro["iterations"], ro["status"])
+            assert relerr(m.solver_state.z[b], o.z) <= 1e-9 and relerr(m.solver_state.v[b], o.v) <= 1e-9
     m.close()
 
 

@@ -428,6 +428,36 @@ def test_sp_corrected_variant(S, O, N, nu, x0s, mb, cap, tol):
     m.close()
 
 
+@pytest.mark.parametrize("N,nx", [(6, 5), (7, 20)])
+def test_build_step_on_the_device(S, O, N, nx):
+    """spock_update_dynamics: the device-side build step (spock_build.hpp: ricatti_offline implicit_l.jl:46-97 + the composite
+    sweep matrices) for new dynamics against a model built on the host from those dynamics: P, K, Rtilde^-1, A + B K to rounding,
+    the same CP iterates (also against the oracle), the closed loop advancing with the new A, B."""
+    import dataclasses
+    tree, cost, dyn, rms, con = S.get_server_heat_specs(N, nx, 2)
+    rng = np.random.default_rng(3)
+    dyn2 = dataclasses.replace(dyn, A=[0.9 * a + 0.01 * rng.standard_normal(a.shape) for a in dyn.A],
+                               B=[b + 0.05 * rng.standard_normal(b.shape) for b in dyn.B])
+    x0 = 0.1 * np.cos(np.arange(nx))
+    ref = S.build_model(tree, cost, dyn2, rms, con, max_iter=60)
+    m = S.build_model(tree, cost, dyn, rms, con, max_iter=60)
+    S.solve_model(m, x0, tol=1e-3); m.reset()
+    m.update_dynamics(dyn2)
+    for which in (0, 1, 2, 3):
+        a, b = m.build_product(which), ref.build_product(which)
+        assert a.shape == b.shape and relerr(a, b) <= 1e-12, which
+    r1 = S.solve_model(m, x0, tol=1e-9); r2 = S.solve_model(ref, x0, tol=1e-9)
+    assert r1["iterations"] == r2["iterations"] == 60
+    assert relerr(m.solver_state.z, ref.solver_state.z) <= 1e-10
+    o = O.Oracle(S.flatten_problem(tree, cost, dyn2, rms, con), O.CP); o.solve(x0, tol=1e-9, max_iter=60)
+    assert relerr(m.solver_state.z, o.z) <= 1e-9
+    w = np.array([[0, 1, 1]])
+    m.reset(); ref.reset()
+    xa, ua, _ = S.mpc_simulation(m, x0, w, tol=1e-3); xb, ub, _ = S.mpc_simulation(ref, x0, w, tol=1e-3)
+    assert np.max(np.abs(xa - xb)) <= 1e-9 and np.max(np.abs(ua - ub)) <= 1e-9
+    m.close(); ref.close()
+
+
 # ---- element-major ("interleaved") batched regime (spock_igroup.hpp): one lane per instance, one wave per tree node -----------
 @pytest.mark.parametrize("N,nu,B,kw", [(7, 5, 70, {}), (8, 2, 64, {"split_stage": 5}), (10, 5, 130, {}), (9, 2, 70, {"split_stage": 2}),
                                        (10, 5, 130, {"stream": "0"})])
@@ -459,6 +489,39 @@ def test_interleaved_layout_matches_oracle(S, O, N, nu, B, kw, monkeypatch):
     rs3 = S.solve_model(m, x0, tol=1e-3)
     assert [r["iterations"] for r in rs3] == [r["iterations"] for r in rs]
     assert np.array_equal(m.solver_state.z, Z) and np.array_equal(m.solver_state.v, V)     # bitwise repeatable
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["shared_dense_costs", "d3_tree", "nx2_nu1", "soc_risk_cone"])
+def test_interleaved_shapes_and_cost_modes(S, O, name):
+    """The role waves of the level-streaming kernels on the other compile-time shapes and cost modes: shared dense cost roots
+    (CM_SHARED), branching factor 3 (three C_c and three L_c waves per workgroup), nx = 2 / nu = 1, a second-order sub-cone in the
+    risk cone; CP against the oracle in SILENT and LOG mode."""
+    rng = np.random.default_rng(5)
+    if name == "shared_dense_costs":
+        tree, cost, dyn, rms, con = S.get_server_heat_specs(6, 5, 2)
+        a = rng.standard_normal((5, 5)); Q = 0.05 * (a @ a.T) / 5 + 0.05 * np.eye(5)
+        specs = (tree, S.Cost([Q], [np.eye(5) + 0.2 * Q], [Q.copy()]), dyn, rms, con)
+    elif name == "d3_tree":
+        specs = S.get_random_linear_specs(5, 3, 2, d=3)
+    elif name == "nx2_nu1":
+        specs = S.get_random_linear_specs(7, 2, 1)
+    else:
+        tree, cost, dyn, _, con = S.get_server_heat_specs(6, 5, 2)
+        E = np.vstack([0.95 * np.eye(2), -np.eye(2), np.ones((1, 2))]); F = np.zeros((5, 2)); b = np.array([0.3, 0.7, 0, 0, 1.0])
+        specs = (tree, cost, dyn, S.get_uniform_rms_v2(E, F, b, S.ConvexCone([(S.CONE_SOC, 3), (S.CONE_NONNEG, 1), (S.CONE_REALS, 1)]), 2, 6), con)
+    flat = S.flatten_problem(*specs)
+    B, nx = 3, flat.nx
+    x0 = 0.1 * (1 + 0.3 * np.arange(B))[:, None] * np.cos(np.arange(nx))[None, :]
+    m = S.build_model(*specs, batch=B, layout="interleaved", max_iter=50, split_stage=2)
+    assert m.sizes.interleaved == 1
+    for verbose, ov in ((S.SILENT, O.SILENT), (S.LOG, O.LOG)):
+        m.reset()
+        rs = S.solve_model(m, x0, tol=1e-4, verbose=verbose)
+        for b in range(B):
+            o = O.Oracle(flat, O.CP); ro = o.solve(x0[b], tol=1e-4, max_iter=50, verbose=ov)
+            assert (rs[b]["iterations"], rs[b]["status"]) == (ro["iterations"], ro["status"])
+            assert relerr(m.solver_state.z[b], o.z) <= 1e-9 and relerr(m.solver_state.v[b], o.v) <= 1e-9
     m.close()
 
 
