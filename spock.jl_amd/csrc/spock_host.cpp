@@ -151,9 +151,10 @@ int choose_split_stage(int N, int d, int nx, int nu, int batch) {
 int choose_split_stage_ilv(int N, int d, int nx) {
     if (!(std::getenv("SPOCK_AMD_ILV_STREAM") && std::getenv("SPOCK_AMD_ILV_STREAM")[0] == '0')) {
         // level-streaming kernels below the split: a small crown (one top group, no mid layers) and everything else streamed.
-        // Measured on MI355X (config 2, 2048 instances): split 3 / 4 / 5 / 6 / 8 -> 2.37 / 2.37 / 2.49 / 2.48 / 2.49 ms per iteration.
-        // (The instance-major kernels of the operator entry points share the split: their subtrees must fit one workgroup.)
-        int t0 = N - 2 < 4 ? N - 2 : 4;
+        // Measured on MI355X (config 2, 2048 instances, one stream): split 3 / 4 / 5 / 6 / 8 -> 2.50 / 2.57 / 2.58 / 2.62 / 2.61 ms per
+        // iteration (bench: 830 k against 809 k iterations/s for 3 against 4).  The smaller the crown the better; what stops at 3
+        // is that the instance-major kernels of the operator entry points share the split and their subtrees must fit one workgroup.
+        int t0 = N - 2 < 3 ? N - 2 : 3;
         while (t0 < N - 2 && group_threads(d, N - t0) > 512) ++t0;
         return t0 < 1 ? 1 : t0;
     }

@@ -14,9 +14,11 @@
 // A workgroup = one wave per role, working through ls_chunk consecutive nodes of the stage with ONE barrier per node (the
 // exchange rows are double-buffered).  Nothing else is shared: x_i comes from zbar (stored by the parent's launch), q of the
 // children from cq, so there are no sweep slots in LDS and no barriers between tree levels -- a tree level is a kernel boundary.
-//   LB   (stages t0 .. N-3, top-down)  forward step + phase B                      roles X, R, C_0 .. C_{d-1}
+//   LB   (stages t0 .. N-3, top-down)  forward step + phase B + the (x_i, u_i) half of the next phase A (c_i, e_i parked in cq /
+//                                      dbuf)                                      roles X, R, C_0 .. C_{d-1}
 //   LBA  (stage N-2)                   forward step + phase B + next phase A + backward step   roles X, R, C_c, L_c
-//   LA   (stages N-3 .. t0, bottom-up) next phase A + backward step on (zbar, vbar)   roles AX (x_i, u_i, sweep), AR (S2)
+//   LA   (stages N-3 .. t0, bottom-up) backward step from c_i, e_i and the children's q (role AX); the [y; s_ch; tau_ch] half of the
+//                                      next phase A with S2 on (zbar, vbar) (role AR)
 //   LA0  (prologue, once per solve)    phase A + backward step of iteration 0 on (z, v), one wave per node (a_local_g)
 // The arithmetic per entry is that of a_local_g / b_local_g / fwd_node / bwd_node (spock_device.hpp), block by block; sums over the
 // children that those accumulate into one register are formed here per role and added afterwards (a different, fixed order).
@@ -116,9 +118,11 @@ SPK_DEV void lv_finish_x_res(const P &p, const ProxScal &ps, LVec ex, int crow, 
     }
 }
 
-// role X behind the barrier, bottom stage: next phase A on (x_i, u_i) (implicit_l.jl:351-373, :399-420), c_i / e_i, backward
-// step with the leaves' W_c q_c, V_c q_c from the roles L_c (implicit_l.jl:584-637) -> q_i to cq, d_i to dbuf
-template <class P, class DB, class CQ>
+// role X behind the barrier: next phase A on (x_i, u_i) (implicit_l.jl:351-373, :399-420) with the children's L'vbar from the roles
+// C_c, then c_i / e_i (a_finish_ce).  Bottom stage (BOT): the backward step with the leaves' W_c q_c, V_c q_c from the roles L_c
+// (implicit_l.jl:584-637) -> q_i to cq, d_i to dbuf.  Other stages: c_i is parked in cq's row of the node and e_i in dbuf's (the
+// d_i of this iteration has been consumed in front of the barrier); LA turns them into q_i, d_i when the children's q exist.
+template <class P, bool BOT, class DB, class CQ>
 SPK_DEV void lv_finish_x_next(const P &p, const Dims &dm, MatPtr M, const ProxScal &ps, LVec ex, int crow, int rL, int node, int stage,
                               DB db, CQ cq, const LvRole<P> &lr) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu;
@@ -132,10 +136,12 @@ SPK_DEV void lv_finish_x_next(const P &p, const Dims &dm, MatPtr M, const ProxSc
     TState<P> s;
     s.stage = stage; s.node = node;
     a_finish_ce(p, dm, M, s, xbar, ubar);
-    SPK_UNROLL for (int c = 0; c < d; ++c) {
-        const int base = rL + c * (nxu + 1);
-        SPK_UNROLL for (int r = 0; r < nx; ++r) s.xb[r] += ex[base + r];
-        SPK_UNROLL for (int r = 0; r < nu; ++r) s.ub[r] -= ex[base + nx + r];
+    if (BOT) {
+        SPK_UNROLL for (int c = 0; c < d; ++c) {
+            const int base = rL + c * (nxu + 1);
+            SPK_UNROLL for (int r = 0; r < nx; ++r) s.xb[r] += ex[base + r];
+            SPK_UNROLL for (int r = 0; r < nu; ++r) s.ub[r] -= ex[base + nx + r];
+        }
     }
     SPK_UNROLL for (int k = 0; k < nu; ++k) db[node * nu + k] = s.ub[k];
     SPK_UNROLL for (int k = 0; k < nx; ++k) cq[node * nx + k] = s.xb[k];
@@ -235,8 +241,8 @@ SPK_DEV void lv_finish_r(const P &p, const Dims &dm, MatPtr M, LVec ex, int crow
 
 // ---- role C_c: the cone block of child c, (v6_j; v3_j, v4_j, v5_j) in SOC(nx+nu+2) (implicit_l.jl:226-272, :854-900) and its L'
 // contributions on (x_i, u_i).  Every load of the block is issued up front (one round trip to memory).  Rows of `ex` from
-// `base` on: [L'dv (nxu)] [L'vbar (nxu), NEXTA] [L'xi_2 (nxu), WX] [tau_j of the next phase A, NEXTA]
-template <class P, bool WX, bool NEXTA, class ZI, class VI, class ZB, class VO, class DB>
+// `base` on: [L'dv (nxu)] [L'vbar (nxu)] [L'xi_2 (nxu), WX] [tau_j of the next phase A, TAU = bottom stage]
+template <class P, bool WX, bool TAU, class ZI, class VI, class ZB, class VO, class DB>
 SPK_DEV void lv_role_c(const P &p, const Dims &dm, MatPtr M, MatPtr SW, ZI z, VI v, ZB zb, VO vo, DB db, int node, int c, const ProxScal &ps,
                        real *mx, LVec ex, int base) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu, i = node;
@@ -284,7 +290,7 @@ SPK_DEV void lv_role_c(const P &p, const Dims &dm, MatPtr M, MatPtr SW, ZI z, VI
     SPK_UNROLL for (int r = 0; r < nu; ++r) vo[dm.o4 + jn * nu + r] = pj[1 + nx + r];
     vo[dm.o5 + jn] = pj[1 + nxu];
     int row = base + nxu;
-    if (NEXTA) {   // L'vbar on x_i, u_i and on tau_j (implicit_l.jl:365-373, :412-420, :432-437)
+    {   // L'vbar on x_i, u_i: the (x_i, u_i) half of the next phase A (implicit_l.jl:365-373, :412-420)
         real ltv[P::MAXNX + P::MAXNU];
         sym_mv<P, false>(nx, SQ, pj + 1, ltv);
         sym_mv<P, false>(nu, SR, pj + 1 + nx, ltv + nx);
@@ -306,7 +312,7 @@ SPK_DEV void lv_role_c(const P &p, const Dims &dm, MatPtr M, MatPtr SW, ZI z, VI
         SPK_UNROLL for (int k = 0; k < nxu; ++k) ex[row + k] = ltx[k];
         row += nxu;
     }
-    if (NEXTA) ex[row] = mgn * (0.5 * pj[1 + nxu] + 0.5 * pj[0]) + zbt;
+    if (TAU) ex[row] = mgn * (0.5 * pj[1 + nxu] + 0.5 * pj[0]) + zbt;   // tau_j of the next phase A (implicit_l.jl:432-437)
     const real x1t = (0.5 * tt[1 + nxu] + 0.5 * tt[0]) + nig * dzt;   // xi_1 on tau_j (implicit_l.jl:432-437)
     spk_resmax<IVec>(mx[0], x1t, mx[3]);
     if (WX) spk_resmax<IVec>(mx[2], (0.5 * lz[1 + nxu] + 0.5 * lz[0]) + x1t, mx[3]);
@@ -397,34 +403,15 @@ SPK_DEV void lv_role_l(const P &p, const Dims &dm, MatPtr M, MatPtr SW, MatPtr B
 }
 
 // ---- LA roles (non-bottom stages, bottom-up): the two independent halves of a_local_g -------------------------------------
-// AX: (x_i, u_i) of (-gamma) L'v + z (implicit_l.jl:351-373, :399-420), c_i / e_i, backward step with the children's q from cq
-template <class P, class ZI, class VI, class DB, class CQ>
-SPK_DEV void lv_role_ax(const P &p, const Dims &dm, MatPtr M, MatPtr SW, ZI z, VI v, DB db, CQ cq, int node, int pos, int stage,
-                        int first_child_stage_node, real gamma) {
-    const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu, i = node;
-    const real mg = -gamma;
+// AX: the backward step of node i (implicit_l.jl:584-637) from c_i, e_i -- parked in cq / dbuf by LB's role X -- and the children's
+// q from cq: q_i = c_i + sum_c W_c q_c back to cq, d_i = e_i - sum_c V_c q_c back to dbuf
+template <class P, class DB, class CQ>
+SPK_DEV void lv_role_ax(const P &p, const Dims &dm, MatPtr SW, DB db, CQ cq, int node, int pos, int stage, int first_child_stage_node) {
+    const int nx = p.nx(), nu = p.nu(), d = p.d(), i = node;
     TState<P> s;
     s.node = i; s.c0 = i * d + 1; s.stage = stage; s.lvl = 0; s.pos = pos; s.kids_leaf = false; s.kids_gleaf = true; s.active = true;
-    real xbar[P::MAXNX], ubar[P::MAXNU];
-    {
-        real acc[P::MAXNX];
-        SPK_UNROLL for (int k = 0; k < nx; ++k) acc[k] = v[dm.o7 + i * nxu + k];
-        SPK_UNROLL for (int c = 0; c < d; ++c) {
-            const int jn = s.c0 + c - 1;
-            sym_mv<P, true>(nx, M + dm.mSqQ + (P::SHARED ? 0 : jn) * nx * nx, v + dm.o3 + jn * nx, acc);
-        }
-        SPK_UNROLL for (int k = 0; k < nx; ++k) xbar[k] = mg * acc[k] + z[dm.zx + i * nx + k];
-    }
-    {
-        real acc[P::MAXNU];
-        SPK_UNROLL for (int k = 0; k < nu; ++k) acc[k] = v[dm.o7 + i * nxu + nx + k];
-        SPK_UNROLL for (int c = 0; c < d; ++c) {
-            const int jn = s.c0 + c - 1;
-            sym_mv<P, true>(nu, M + dm.mSqR + (P::SHARED ? 0 : jn) * nu * nu, v + dm.o4 + jn * nu, acc);
-        }
-        SPK_UNROLL for (int k = 0; k < nu; ++k) ubar[k] = mg * acc[k] + z[dm.zu + i * nu + k];
-    }
-    a_finish_ce(p, dm, M, s, xbar, ubar);
+    SPK_UNROLL for (int k = 0; k < nx; ++k) s.xb[k] = cq[(long)i * nx + k];
+    SPK_UNROLL for (int k = 0; k < nu; ++k) s.ub[k] = db[i * nu + k];
     bwd_node(p, dm, SW, 0, LVec{nullptr}, cq + (long)first_child_stage_node * nx, cq + (long)i * nx, s);
     SPK_UNROLL for (int k = 0; k < nu; ++k) db[i * nu + k] = s.dd[k];
 }
@@ -510,7 +497,7 @@ SPK_DEV void ilevel_body(X &x, const KArgs &a, const real *zin_, const real *vin
             const IVec db = vw(dbuf, n_db, tid), cqv = vw(cq, n_cq, tid);
             for (int pos = lo + (wave >> 1); pos < hi; pos += (nW >> 1)) {
                 const int node = first + pos;
-                if (role == 0) lv_role_ax(p, dm, M, SW, zb, vb, db, cqv, node, pos, stage, first_child, gamma);
+                if (role == 0) lv_role_ax(p, dm, SW, db, cqv, node, pos, stage, first_child);
                 else lv_role_ar(p, dm, M, zb, vb, zn, node, gamma);
             }
         });
@@ -520,9 +507,9 @@ SPK_DEV void ilevel_body(X &x, const KArgs &a, const real *zin_, const real *vin
     // ---- LB / LBA: one wave per role, one node at a time, one barrier per node ---------------------------------------------
     constexpr bool BOT = (MODE == MODE_LBA);
     const int rows = BOT ? lba_exchange_rows(nx, nu, d, WX) : lb_exchange_rows(nx, nu, d, WX);
-    // rows of one exchange buffer: per child c a block of `crow` rows from role C_c, [L'dv | L'vbar (bottom) | L'xi_2 (LOG mode) |
+    // rows of one exchange buffer: per child c a block of `crow` rows from role C_c, [L'dv | L'vbar | L'xi_2 (LOG mode) |
     // tau_j (bottom)], then -- bottom -- per child [W_c q_c | V_c q_c | s_c] from role L_c
-    const int crow = (1 + (BOT ? 1 : 0) + (WX ? 1 : 0)) * nxu + (BOT ? 1 : 0), oX = (BOT ? 2 : 1) * nxu, rL = d * crow;
+    const int crow = (2 + (WX ? 1 : 0)) * nxu + (BOT ? 1 : 0), oX = 2 * nxu, rL = d * crow;
     // Every role is ONE branch that contains its part in front of the barrier, the barrier and its finishing part: what a role
     // carries across the barrier (LvRole) is then live in that role's branch only.  (x.phased: the GPU policy runs the body once
     // with pre = post = true and sync() = the workgroup barrier; the host emulation runs it per thread with pre, then with post.)
@@ -540,7 +527,7 @@ SPK_DEV void ilevel_body(X &x, const KArgs &a, const real *zin_, const real *vin
                 x.sync();
                 if (post) {
                     lv_finish_x_res<P, WX>(p, ps, ex, crow, oX, st.mx, st.lr);
-                    if (BOT) lv_finish_x_next(p, dm, M, ps, ex, crow, rL, node, stage, db, vw(cq, n_cq, tid), st.lr);
+                    lv_finish_x_next<P, BOT>(p, dm, M, ps, ex, crow, rL, node, stage, db, vw(cq, n_cq, tid), st.lr);
                 }
             } else if (role == 1) {
                 if (pre) lv_role_r<P, WX, BOT>(p, dm, M, z, v, zo, vo, node, ps, st.mx, st.lr);

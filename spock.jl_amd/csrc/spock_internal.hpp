@@ -233,11 +233,11 @@ struct IlvGeo {
 IlvGeo ilv_geometry(int mode, const Dims &dm, int level = 0, int want_xi = 0);
 // level-streaming kernels (spock_ilevel.hpp): role waves per workgroup, rows (64 doubles each) of ONE LDS exchange buffer
 // (the kernels double-buffer it over the nodes of a chunk).  LBA rows: per child, role C_c [L'dv | L'vbar | L'xi_2 on (x_i, u_i) | tau_c],
-// role L_c [W_c q_c | V_c q_c | s_c];  LB rows: per child, role C_c [L'dv | L'xi_2 on (x_i, u_i)]
+// role L_c [W_c q_c | V_c q_c | s_c];  LB rows: per child, role C_c [L'dv | L'vbar | L'xi_2 on (x_i, u_i)]
 int ilevel_waves(int mode, const Dims &dm);
 // (the L'xi_2 rows exist in the LOG-mode kernel variants only: want_xi)
 constexpr int lba_exchange_rows(int nx, int nu, int d, bool wx) { return d * ((wx ? 3 : 2) * (nx + nu) + 1) + d * (nx + nu + 1); }
-constexpr int lb_exchange_rows(int nx, int nu, int d, bool wx) { return d * (wx ? 2 : 1) * (nx + nu); }
+constexpr int lb_exchange_rows(int nx, int nu, int d, bool wx) { return d * (wx ? 3 : 2) * (nx + nu); }
 int ilevel_ex_doubles(int mode, const Dims &dm, int want_xi);
 
 // ---- kernel launchers (spock_kernels.hip) ---------------------------------------------------------

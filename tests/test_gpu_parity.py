@@ -525,6 +525,29 @@ def test_interleaved_shapes_and_cost_modes(S, O, name):
     m.close()
 
 
+def test_interleaved_layout_fp32_library(S, O):
+    """The element-major kernels (crown group + level-streaming kernels with their role waves) in libspock_amd_f32.so: rows of
+    64 floats in HBM and LDS.  Against the fp64 oracle at single-precision tolerances: 60 iterations, and a solve to tol 1e-3."""
+    specs = S.get_server_heat_specs(7, 5, 2, nu=5)
+    flat = S.flatten_problem(*specs)
+    B = 70
+    x0 = 0.1 * (1 + 0.02 * np.arange(B))[:, None] * np.ones((B, 5))
+    m = S.build_model(*specs, batch=B, max_iter=60, layout="interleaved", dtype="f32", split_stage=3)
+    assert m.dtype == "f32" and m.sizes.interleaved == 1
+    S.solve_model(m, x0, tol=0.0)
+    for b in (0, 37, 69):
+        o = O.Oracle(flat, O.CP); o.solve(x0[b], tol=0.0, max_iter=60)
+        assert relerr(m.solver_state.z[b], o.z) <= 2e-5 and relerr(m.solver_state.v[b], o.v) <= 2e-5
+    m.close()
+    m = S.build_model(*specs, batch=B, max_iter=1200, layout="interleaved", dtype="f32", split_stage=3)
+    rs = S.solve_model(m, x0, tol=1e-3)
+    for b in (0, 69):
+        o = O.Oracle(flat, O.CP); ro = o.solve(x0[b], tol=1e-3, max_iter=1200)
+        assert rs[b]["status"] == ro["status"] == 0 and abs(rs[b]["iterations"] - ro["iterations"]) <= max(2, ro["iterations"] // 50)
+        assert relerr(m.solver_state.z[b], o.z) <= 2e-3
+    m.close()
+
+
 def test_interleaved_full_size_cfg2(S, O):
     """BASELINE config 2 at full size in the benchmark's regime (element-major, 3 layers of groups, 4 tile groups on their own
     streams): 48 CP iterations of 256 instances, three of them against the oracle; NaN input ends one instance with SPOCK_NAN

@@ -18,7 +18,7 @@ os.environ["KOBJ"] = obj
 subprocess.call([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "ilevel", "5, 2>"])
 if not os.environ.get("NOLINK"):
     # host-side objects: compiled here when stale (seconds); the instance-major kernels come from the last regular build
-    others = [os.path.join(b.HERE, "build", "spock_kernels.hip.o"), os.path.join(b.HERE, "build", "spock_ikernels.hip.o")]
+    others = [os.path.join(b.HERE, "build", s_) for s_ in ("spock_kernels.hip.o", "spock_ikernels.hip.o", "spock_bkernels.hip.o")]
     for src in ("spock_abi.cpp", "spock_host.cpp", "spock_rt_hip.cpp"):
         o = os.path.join(out_dir, "host_" + src + ".o")
         deps = [os.path.join(b.CSRC, src)] + [os.path.join(b.CSRC, h) for h in b.DEPS[src]]
