@@ -375,6 +375,29 @@ def main(argv=None):
                 single["cpu_oracle_ms_to_tol_nu5"] = round(dt5 * 1e3, 1)
                 single["cpu_oracle_iterations_nu5"] = ro["iterations"]
             out["single_instance"] = single
+            # BASELINE config 5 (random linear nx = 64, nu = 16, N = 15, 16 384 leaves): the S1 sweep levels run on the fp64
+            # matrix cores (v_mfma_f64_16x16x4_f64).  Flops per CP iteration from SURVEY.md section 8d.
+            if args.tree_N >= 13:
+                sp5 = S.get_random_linear_specs(15, 64, 16)
+                f5 = S.flatten_problem(*sp5)
+                mc = S.build_model(*sp5, S.SolverOptions(S.CP, None), batch=1, device=dev_index, max_iter=60, graph_iters=60, L_norm="auto")
+                xc = 0.1 * np.cos(np.arange(64))
+                S.solve_model(mc, xc, tol=0.0)
+                rc = S.solve_model(mc, xc, tol=0.0)
+                mc.close()
+                nn5, n5, nl5, ny5, dd = f5.nn, f5.n, f5.nl, f5.ny, f5.d
+                l_mac = nn5 * ny5 + (n5 - 1) * (64 + 16) + nl5 * 64                       # diagonal cost roots
+                s1_mac = nn5 * (16 * 16 + 2 * 64 * 16 + dd * (3 * 64 * 64 + 3 * 64 * 16))
+                s2_mac = nn5 * (ny5 + 2 * dd) ** 2
+                flops = 2.0 * (4 * l_mac + s1_mac + s2_mac)
+                ms_it = rc["solve_ms"] / rc["iterations"]
+                FP64_PEAK = 78.6   # TFLOP/s: AMD's public fp64 figure for MI355X (vector = matrix rate), as SURVEY.md 8d has it; the local guide gives none
+                out["cfg5"] = {"workload": "random linear nx=64 nu=16 d=2 N=15 (16384 leaves), one instance, CP", "ms_per_iteration": round(ms_it, 4),
+                               "flops_per_iteration": flops,
+                               "roofline": {"bound": "mfma", "kernel": "S1 sweep levels on v_mfma_f64_16x16x4_f64 (bwd_level_mfma / fwd_level_mfma)",
+                                            "achieved": round(flops / (ms_it * 1e-3) / 1e12, 3), "peak": FP64_PEAK, "unit": "TFLOP/s",
+                                            "frac": round(flops / (ms_it * 1e-3) / 1e12 / FP64_PEAK, 4), "traffic": None,
+                                            "note": "a single instance: bound by the chain of 2 x 14 dependent tree levels and two launch boundaries, not by either roofline"}}
             # problems/s: 64 independent instances of the convergent (nu = 5) tree, different x0, solved to tol 1e-3 as one batch
             probs = {}
             X = 0.1 * (1.0 + 0.01 * np.arange(64))[:, None] * np.ones((64, NX))

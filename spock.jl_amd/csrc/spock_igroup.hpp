@@ -64,6 +64,7 @@ struct IState {
     real mx[4];   // xi_1, xi_2, xi maxima and the NaN poison accumulator (spk_resmax)
     bool live;
     LvRole<P> lr;
+    ProxScal ps;   // level kernels: the instance's step sizes and their reciprocals, formed once per kernel (three divisions)
 };
 
 SPK_DEV int igroup_nonleaf(int d, int stages) {   // non-leaf nodes of a complete d-ary tree with `stages` stages

@@ -506,6 +506,7 @@ SPK_DEV void ilevel_body(X &x, const KArgs &a, const real *zin_, const real *vin
 
     // ---- LB / LBA: one wave per role, one node at a time, one barrier per node ---------------------------------------------
     constexpr bool BOT = (MODE == MODE_LBA);
+    x.each([&](int tid, IState<P> &st) SPK_ILAMBDA { if (st.live) st.ps = make_ps(a.ctl[tile * 64 + (tid & 63)]); });
     const int rows = BOT ? lba_exchange_rows(nx, nu, d, WX) : lb_exchange_rows(nx, nu, d, WX);
     // rows of one exchange buffer: per child c a block of `crow` rows from role C_c, [L'dv | L'vbar | L'xi_2 (LOG mode) |
     // tau_j (bottom)], then -- bottom -- per child [W_c q_c | V_c q_c | s_c] from role L_c
@@ -518,7 +519,7 @@ SPK_DEV void ilevel_body(X &x, const KArgs &a, const real *zin_, const real *vin
         x.phased([&](int tid, IState<P> &st, bool pre, bool post) SPK_ILAMBDA {
             if (!st.live) return;
             const int role = spk_uniform(tid >> 6);
-            const ProxScal ps = make_ps(a.ctl[tile * 64 + (tid & 63)]);
+            const ProxScal &ps = st.ps;
             const IVec z = vw(zin, dm.nz, tid), v = vw(vin, dm.nv, tid), zo = vw(zout, dm.nz, tid), vo = vw(vout, dm.nv, tid);
             const IVec db = vw(dbuf, n_db, tid);
             const LVec ex = LVec{x.lds() + (long)buf * rows * 64 + (tid & 63)};
