@@ -98,7 +98,7 @@ typedef struct {
                            * negative -> ||L||^2 in closed form (the reference's `Todo: L norm must be computed efficiently!`) */
     int32_t max_iter;     /* 0 -> reference default: 5000 (cp.jl:190) / 1000 (sp.jl:360) */
     int32_t graph_iters;  /* iterations captured per hipGraph replay; 0 = choose */
-    int32_t batch_layout; /* layout of the batch in HBM: 0 = choose (element-major from 1024 instances on, CP and the compile-time
+    int32_t batch_layout; /* layout of the batch in HBM: 0 = choose (element-major from 320 instances on, CP and the compile-time
                            * shapes), 1 = instance-major z[b][nz] (one thread per tree node), 2 = element-major z[e][batch]
                            * (one lane per instance, one wave per tree node).  Invisible at this boundary: every array that
                            * crosses it is instance-major. */

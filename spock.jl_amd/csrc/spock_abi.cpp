@@ -573,16 +573,17 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     int split = o ? o->split_stage : 0;
     if (const char *e = std::getenv("SPOCK_AMD_SPLIT_STAGE")) split = std::atoi(e);
 
-    // Layout of the batch: element-major (one lane per instance, spock_igroup.hpp) needs tiles of 64 instances and enough of them
-    // to fill the chip with one wave per tree node: measured on MI355X (config 2) it overtakes the instance-major kernels between
-    // 512 and 1024 instances (64 instances: 188 against 520 problems/s; 1024: 648 k against 545 k iterations/s).  Chosen from 1024
-    // instances on, for CP and the compile-time shapes; batch_layout / SPOCK_AMD_ILV override.
+    // Layout of the batch: element-major (one lane per instance, spock_igroup.hpp / spock_ilevel.hpp) needs tiles of 64 instances and
+    // enough of them to fill the chip.  Measured on MI355X (config 2, iterations/s instance-major -> element-major): 64 instances
+    // 346 k -> 181 k, 128: 401 k -> 307 k, 256: 464 k -> 475 k, 384: 472 k -> 541 k, 512: 495 k -> 573 k, 1024: 519 k -> 722 k,
+    // 2048: 527 k -> 800 k.  Chosen from 320 instances (five tiles) on, for CP and the compile-time shapes; batch_layout /
+    // SPOCK_AMD_ILV override.
     int layout = o ? o->batch_layout : 0;
     if (const char *e = std::getenv("SPOCK_AMD_ILV")) layout = (e[0] == '1') ? 2 : 1;
     if (layout < 0 || layout > 2) { delete h; return fail(SPOCK_ERR_BAD_ARG, "batch_layout must be 0 (choose), 1 (instance-major) or 2 (element-major)"); }
     const bool ilv_possible = alg == SPOCK_ALG_CP && N >= 3 && have_static_variant(nx, nu, d, ny) && hp.nQ == 1 && hp.nR == 1 && hp.nQN == 1 && hp.n_rms == 1;
     if (layout == 2 && !ilv_possible) { delete h; return fail(SPOCK_ERR_UNSUPPORTED, "the element-major batch layout exists for CP, the compile-time shapes and shared cost matrices"); }
-    bool want_ilv = ilv_possible && (layout == 2 || (layout == 0 && h->batch >= 1024));
+    bool want_ilv = ilv_possible && (layout == 2 || (layout == 0 && h->batch >= 320));
 
     bool unsupported = false;
     std::string msg;

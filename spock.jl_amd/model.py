@@ -244,7 +244,7 @@ class Model:
 def build_model(scen_tree, cost, dynamics, rms, constraints, solver_options: SolverOptions = SolverOptions(CP, None),
                 **kw) -> Model:
     """model.jl:273-297.  Keyword extensions: batch, device, L_norm, max_iter, split_stage, graph_iters, lib_path, layout
-    ("instance" / "interleaved": how the batch is laid out in HBM; default: interleaved from 1024 instances on), dtype ("f64", or
+    ("instance" / "interleaved": how the batch is laid out in HBM; default: interleaved from 320 instances on), dtype ("f64", or
     "f32": libspock_amd_f32.so, the same kernels in single precision -- the reference itself is Float64 only)."""
     if solver_options.algorithm not in (AlgorithmOptions.CP, AlgorithmOptions.SP):
         raise ValueError("This combination of solver options is not supported.")

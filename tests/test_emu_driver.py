@@ -623,7 +623,7 @@ def test_interleaved_layout_falls_back_or_refuses(S, emu):
     m = S.build_model(*specs2, lib_path=emu, batch=1024)
     assert m.sizes.interleaved == 0
     m.close()
-    m = S.build_model(*specs, lib_path=emu, batch=1024)    # CP, compile-time shape, >= 1024 instances: element-major by default
+    m = S.build_model(*specs, lib_path=emu, batch=1024)    # CP, compile-time shape, >= 320 instances: element-major by default
     assert m.sizes.interleaved == 1
     m.close()
     m = S.build_model(*specs, lib_path=emu, batch=64)      # fewer: the instance-major kernels (faster there)
