@@ -410,6 +410,18 @@ def main(argv=None):
                 probs[name] = {"instances": 64, "ms": round(dtb * 1e3, 2), "problems_per_s": round(64 / dtb, 1),
                                "iterations_max": max(q["iterations"] for q in rb)}
                 mb.close()
+            # the same with a batch that fills the chip: 2048 instances, element-major layout (finished instances freeze lane by lane)
+            if args.tree_N >= 13:
+                XB = 0.1 * (1.0 + 0.0005 * np.arange(B))[:, None] * np.ones((B, NX))
+                mb = S.build_model(*specs5, S.SolverOptions(S.CP, None), batch=B, device=dev_index)
+                S.solve_model(mb, XB, tol=1e-3); mb.reset()
+                torch.cuda.synchronize(); t = time.perf_counter(); rb = S.solve_model(mb, XB, tol=1e-3); torch.cuda.synchronize()
+                dtb = time.perf_counter() - t
+                assert all(q["status"] == 0 for q in rb)
+                probs["cp_large_batch"] = {"instances": B, "layout": "element-major" if mb.sizes.interleaved else "instance-major",
+                                           "ms": round(dtb * 1e3, 2), "problems_per_s": round(B / dtb, 1),
+                                           "iterations_max": max(q["iterations"] for q in rb), "iterations_min": min(q["iterations"] for q in rb)}
+                mb.close()
             out["problems_to_tol_1e-3_nu5"] = probs
 
     if rank == 0:

@@ -590,6 +590,24 @@ def test_emulated_interleaved_shapes_and_cost_modes(S, O, emu, name):
     m.close()
 
 
+def test_emulated_profile_sequence_lists_the_launches_of_an_iteration(S, emu):
+    """spock_profile_sequence: one entry per launch of a CP iteration, in launch order -- the crown, the level kernels LB top-down,
+    the bottom stage's LBA, LA bottom-up; the iterate left behind is the one `reps` iterations further on."""
+    specs = S.get_server_heat_specs(8, 5, 2, nu=2)
+    m = S.build_model(*specs, lib_path=emu, batch=3, layout="interleaved", max_iter=12)
+    x0 = np.full((3, 5), 0.1)
+    S.solve_model(m, x0, tol=0.0)
+    t0 = m.sizes.split_stage
+    seq = m.profile_sequence(2)
+    assert [(n, lv) for n, lv, _ in seq] == [("crown", 0)] + [("lb", t) for t in range(t0, 6)] + [("lba", 6)] + [("la", t) for t in range(5, t0 - 1, -1)]
+    assert all(ms >= 0.0 for _, _, ms in seq)
+    z14 = m.solver_state.z.copy()
+    ref = S.build_model(*specs, lib_path=emu, batch=3, layout="interleaved", max_iter=14)
+    S.solve_model(ref, x0, tol=0.0)
+    assert relerr(z14, ref.solver_state.z) <= 1e-12
+    m.close(); ref.close()
+
+
 def test_emulated_interleaved_equals_instance_major_and_mpc(S, O, emu):
     """Same problem, both layouts: identical iteration counts and iterates to rounding; the closed loop on the device works on
     either layout (spock_mpc_simulate reads u_0 with the layout's stride)."""

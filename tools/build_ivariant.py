@@ -13,12 +13,13 @@ out_dir = os.path.join(ROOT, "exp"); os.makedirs(out_dir, exist_ok=True)
 obj = os.path.join(out_dir, f"ikernels_{name}.o")
 flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-variable", "-Wno-cuda-compat",
          "-DSPOCK_STATIC_SHAPES(X)=X(5,2,2,5)"] + extra
-subprocess.check_call([b._hipcc()] + flags + ["-c", os.path.join(b.CSRC, "spock_lkernels.hip"), "-o", obj])
+SRC = os.environ.get("IVARIANT_SRC", "spock_lkernels.hip")    # IVARIANT_SRC=spock_ikernels.hip: the group kernels (crown) instead
+subprocess.check_call([b._hipcc()] + flags + ["-c", os.path.join(b.CSRC, SRC), "-o", obj])
 os.environ["KOBJ"] = obj
 subprocess.call([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "ilevel", "5, 2>"])
 if not os.environ.get("NOLINK"):
     # host-side objects: compiled here when stale (seconds); the instance-major kernels come from the last regular build
-    others = [os.path.join(b.HERE, "build", s_) for s_ in ("spock_kernels.hip.o", "spock_ikernels.hip.o", "spock_bkernels.hip.o")]
+    others = [os.path.join(b.HERE, "build", s_) for s_ in ("spock_kernels.hip.o", "spock_ikernels.hip.o", "spock_lkernels.hip.o", "spock_bkernels.hip.o") if s_ != SRC + ".o"]
     for src in ("spock_abi.cpp", "spock_host.cpp", "spock_rt_hip.cpp"):
         o = os.path.join(out_dir, "host_" + src + ".o")
         deps = [os.path.join(b.CSRC, src)] + [os.path.join(b.CSRC, h) for h in b.DEPS[src]]
