@@ -570,16 +570,20 @@ SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
 #ifndef SPOCK_HOST_EMU
 typedef double spk_v4d __attribute__((ext_vector_type(4)));
 
-// instantiated shapes (nx, nu): BASELINE config 5
-SPK_DEV bool mfma_sweep_applies(int nx, int nu, int d) { return kRealIsDouble && nx == 64 && nu == 16 && d == 2; }
+// instantiated shapes (nx, nu, d): BASELINE config 5 (64, 16, 2), config 4 (20, 20, 2) and config 3 (20, 20, 3) -- for nx = nu = 20
+// the row tiles are padded to 16 and the rows past nx / nu masked
+SPK_DEV bool mfma_sweep_applies(int nx, int nu, int d) {
+    return kRealIsDouble && ((nx == 64 && nu == 16 && d == 2) || (nx == 20 && nu == 20 && (d == 2 || d == 3)));
+}
 
 // One wave owns a ROW tile m of the level's product and keeps its matrix fragments (KF k-steps: one 8-byte element per lane
 // each) in registers while it runs over the level's node tiles: the fragments are fetched from L2 once per level and wave --
 // their latency (the sweep is a chain of small dependent levels) is paid once, not per node tile.
+// (row_ok: this lane's matrix row exists -- the last row tile of a shape that is not a multiple of 16 is padded with zeros)
 template <int KF, class MPT>
-SPK_DEV void mfma_load_frags(real (&af)[KF], MPT Mx, long ld, int kq, int nk4, int k_base) {
+SPK_DEV void mfma_load_frags(real (&af)[KF], MPT Mx, long ld, int kq, int nk4, int k_base, bool row_ok = true) {
 #pragma unroll
-    for (int q = 0; q < KF; ++q) af[q] = (q < nk4) ? Mx[(long)(k_base + 4 * q + kq) * ld] : 0.;
+    for (int q = 0; q < KF; ++q) af[q] = (row_ok && q < nk4) ? Mx[(long)(k_base + 4 * q + kq) * ld] : 0.;
 }
 
 // NXC / NUC / DC: compile-time nx / nu / d of the instantiation (64 / 16 / 2 for BASELINE config 5).  Work item = (row tile m,
@@ -591,7 +595,7 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
     constexpr int nx = NXC, nu = NUC, d = DC, KQ = NXC / 4;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    constexpr int mq = nx / 16, mt = mq + nu / 16;
+    constexpr int mq = (nx + 15) / 16, mt = mq + (nu + 15) / 16;
     const int ntile = (cnt + 15) / 16;
     int nsplit = nwaves / mt;
     if (nsplit > ntile) nsplit = ntile;
@@ -599,11 +603,12 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
     for (int it = wave; it < mt * nsplit; it += nwaves) {
         const int m = it % mt, sp = it / mt;
         const bool isq = m < mq;
-        const int row0 = isq ? m * 16 : (m - mq) * 16, ld = isq ? nx : nu;
+        const int row0 = isq ? m * 16 : (m - mq) * 16, ld = isq ? nx : nu, nrow = isq ? nx : nu;
+        const bool row_ok = row0 + j < nrow;
         real af[DC][KQ];
 #pragma unroll
         for (int c = 0; c < d; ++c)
-            mfma_load_frags<KQ>(af[c], (isq ? SW + dm.sw_oW + c * nx * nx : SW + dm.sw_oV + c * nu * nx) + (row0 + j), ld, kq, KQ, 0);
+            mfma_load_frags<KQ>(af[c], (isq ? SW + dm.sw_oW + c * nx * nx : SW + dm.sw_oV + c * nu * nx) + (row_ok ? row0 + j : 0), ld, kq, KQ, 0, row_ok);
         for (int nt = sp; nt < ntile; nt += nsplit) {
             const int pos = nt * 16 + j;
             const bool valid = pos < cnt;
@@ -622,6 +627,7 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int r = row0 + kq + 4 * reg;
+                    if (r >= nrow) continue;
                     if (isq) L.XQ[(long)li * nx + r] += acc[reg];
                     else L.ED[(long)li * nu + r] -= acc[reg];
                 }
@@ -636,7 +642,7 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
     constexpr int nx = NXC, nu = NUC, d = DC, KQ = NXC / 4, KU = NUC / 4;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    constexpr int mq = nx / 16, mu = nu / 16;
+    constexpr int mq = (nx + 15) / 16, mu = (nu + 15) / 16;
     constexpr int mt = d * mq + mu;
     const int ntile = (cnt + 15) / 16;
     int nsplit = nwaves / mt;
@@ -645,13 +651,15 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
     for (int it = wave; it < mt * nsplit; it += nwaves) {
         const int m = it % mt, sp = it / mt;
         const bool isx = m < d * mq;
-        const int c = isx ? m / mq : 0, row0 = isx ? (m - c * mq) * 16 : (m - d * mq) * 16;
+        const int c = isx ? m / mq : 0, row0 = isx ? (m - c * mq) * 16 : (m - d * mq) * 16, nrow = isx ? nx : nu;
+        const bool row_ok = row0 + j < nrow;
+        const int rj = row_ok ? row0 + j : 0;
         real af[KQ], bf[KU];
         if (isx) {
-            mfma_load_frags<KQ>(af, SW + dm.sw_oABK + c * nx * nx + (row0 + j), nx, kq, KQ, 0);
-            mfma_load_frags<KU>(bf, Bm + slot_event(c, d) * nx * nu + (row0 + j), nx, kq, KU, 0);
+            mfma_load_frags<KQ>(af, SW + dm.sw_oABK + c * nx * nx + rj, nx, kq, KQ, 0, row_ok);
+            mfma_load_frags<KU>(bf, Bm + slot_event(c, d) * nx * nu + rj, nx, kq, KU, 0, row_ok);
         } else {
-            mfma_load_frags<KQ>(af, SW + dm.sw_oK + (row0 + j), nu, kq, KQ, 0);
+            mfma_load_frags<KQ>(af, SW + dm.sw_oK + rj, nu, kq, KQ, 0, row_ok);
 #pragma unroll
             for (int q = 0; q < KU; ++q) bf[q] = 0.;
         }
@@ -675,11 +683,11 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
                 if (valid) {
                     real *dst = kids_gleaf ? L.XL + (long)(posv * d + c) * nx : L.XQ + (long)(li * d + 1 + c) * nx;
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) dst[row0 + kq + 4 * reg] = acc[reg];
+                    for (int reg = 0; reg < 4; ++reg) { const int r = row0 + kq + 4 * reg; if (r < nx) dst[r] = acc[reg]; }
                 }
             } else if (valid) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) { const int r = row0 + kq + 4 * reg; L.UL[(long)li * nu + r] = acc[reg] + di[r]; }
+                for (int reg = 0; reg < 4; ++reg) { const int r = row0 + kq + 4 * reg; if (r < nu) L.UL[(long)li * nu + r] = acc[reg] + di[r]; }
             }
         }
     }

@@ -282,11 +282,26 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     x.each([&](int, TState<P> &s) { if (s.tn_li >= 0 && s.tn_lvl == l) bwd_team_reg(p, stages, tl, s); });
                 } else if (lds_mats) {
                     const real *SW = lm + l * dm.sw_stride;
+#ifndef SPOCK_HOST_EMU
+                    // (nx = nu = 20: the stage's matrices are staged in LDS; the fragments come from there)
+                    const bool mf20 = use_mfma && nx == 20;
+                    if constexpr (P::MFMA_SWEEP) { if (mf20) {
+                        if (d == 2) x.each([&](int tid, TState<P> &) { bwd_level_mfma<20, 20, 2>(p, dm, SW, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                        else x.each([&](int tid, TState<P> &) { bwd_level_mfma<20, 20, 3>(p, dm, SW, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                    } }
+                    if (!mf20)
+#endif
                     x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 } else {
                     const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
 #ifndef SPOCK_HOST_EMU
-                    if constexpr (P::MFMA_SWEEP) { if (use_mfma) { x.each([&](int tid, TState<P> &) { bwd_level_mfma<64, 16, 2>(p, dm, SW, lfirst, cnt, l == stages - 2, tid, nthr, tl); }); } }
+                    if constexpr (P::MFMA_SWEEP) {
+                        if (use_mfma) {
+                            if (nx == 64) x.each([&](int tid, TState<P> &) { bwd_level_mfma<64, 16, 2>(p, dm, SW, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                            else if (d == 2) x.each([&](int tid, TState<P> &) { bwd_level_mfma<20, 20, 2>(p, dm, SW, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                            else x.each([&](int tid, TState<P> &) { bwd_level_mfma<20, 20, 3>(p, dm, SW, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                        }
+                    }
                     if (!use_mfma)
 #endif
                     x.each([&](int tid, TState<P> &) { bwd_level_team(p, dm, SW, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
@@ -367,11 +382,25 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     x.each([&](int, TState<P> &s) { if (s.tn_li >= 0 && s.tn_lvl == l) fwd_team_reg(p, stages, tl, s); });
                 } else if (lds_mats) {
                     const real *SW = lm + l * dm.sw_stride;
+#ifndef SPOCK_HOST_EMU
+                    const bool mf20 = use_mfma && nx == 20;
+                    if constexpr (P::MFMA_SWEEP) { if (mf20) {
+                        if (d == 2) x.each([&](int tid, TState<P> &) { fwd_level_mfma<20, 20, 2>(p, dm, SW, lmB, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                        else x.each([&](int tid, TState<P> &) { fwd_level_mfma<20, 20, 3>(p, dm, SW, lmB, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                    } }
+                    if (!mf20)
+#endif
                     x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, lmB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });
                 } else {
                     const MatPtr SW = M + dm.mSweep + (root_stage + l) * dm.sw_stride;
 #ifndef SPOCK_HOST_EMU
-                    if constexpr (P::MFMA_SWEEP) { if (use_mfma) { x.each([&](int tid, TState<P> &) { fwd_level_mfma<64, 16, 2>(p, dm, SW, gB, lfirst, cnt, l == stages - 2, tid, nthr, tl); }); } }
+                    if constexpr (P::MFMA_SWEEP) {
+                        if (use_mfma) {
+                            if (nx == 64) x.each([&](int tid, TState<P> &) { fwd_level_mfma<64, 16, 2>(p, dm, SW, gB, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                            else if (d == 2) x.each([&](int tid, TState<P> &) { fwd_level_mfma<20, 20, 2>(p, dm, SW, gB, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                            else x.each([&](int tid, TState<P> &) { fwd_level_mfma<20, 20, 3>(p, dm, SW, gB, lfirst, cnt, l == stages - 2, tid, nthr, tl); });
+                        }
+                    }
                     if (!use_mfma)
 #endif
                     x.each([&](int tid, TState<P> &) { fwd_level_team(p, dm, SW, gB, lfirst, cnt, l == stages - 2, team, tid, nthr, tl); });

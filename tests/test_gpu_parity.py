@@ -428,6 +428,31 @@ def test_sp_corrected_variant(S, O, N, nu, x0s, mb, cap, tol):
     m.close()
 
 
+@pytest.mark.parametrize("N,d,kw", [(7, 2, {}), (6, 2, {"split_stage": 2}), (5, 3, {}), (6, 3, {"split_stage": 3})])
+def test_mfma_sweep_levels_nx20(S, O, N, d, kw):
+    """nx = nu = 20 (BASELINE configs 3 and 4): the S1 sweep levels on v_mfma_f64_16x16x4_f64 with row tiles padded from 20 to 32
+    rows and the matrices staged in LDS; narrow levels (1, 2, 3, 4, 8, 9, 27 nodes: partial node tiles), a batch of three, crown and
+    subtree kernels: 40 CP iterations and an SP solve against the oracle."""
+    p_ref = [0.3, 0.7] if d == 2 else [0.2, 0.3, 0.5]
+    specs = S.get_server_heat_specs(N, 20, d, p_ref=p_ref)
+    flat = S.flatten_problem(*specs)
+    x0 = 0.1 * (1 + 0.2 * np.arange(3))[:, None] * np.cos(np.arange(20))[None, :]
+    L = 1.05 * S.L_norm_sq(specs[0], specs[1], specs[3])
+    m = S.build_model(*specs, batch=3, max_iter=40, L_norm=L, **kw)
+    rs = S.solve_model(m, x0, tol=0.0)
+    for b in range(3):
+        o = O.Oracle(flat, O.CP); o.L_norm = L; o.solve(x0[b], tol=0.0, max_iter=40)
+        assert rs[b]["iterations"] == 40 and relerr(m.solver_state.z[b], o.z) <= 1e-10 and relerr(m.solver_state.v[b], o.v) <= 1e-10
+    m.close()
+    ms = S.build_model(*specs, S.SolverOptions(S.SP, None), L_norm=L, **kw)
+    r = S.solve_model(ms, x0[0], tol=1e-3, verbose=S.LOG)
+    o = O.Oracle(flat, O.SP); o.L_norm = L; ro = o.solve(x0[0], tol=1e-3, verbose=O.LOG, history=1100)
+    h = ms.history(0)
+    n = min(20, len(h["xi"]), len(ro["hist_xi"]))
+    assert r["status"] == ro["status"] == 0 and np.max(np.abs(h["xi"][:n] - ro["hist_xi"][:n]) / ro["hist_xi"][:n]) <= 1e-6
+    ms.close()
+
+
 @pytest.mark.parametrize("N,nx", [(6, 5), (7, 20)])
 def test_build_step_on_the_device(S, O, N, nx):
     """spock_update_dynamics: the device-side build step (spock_build.hpp: ricatti_offline implicit_l.jl:46-97 + the composite
