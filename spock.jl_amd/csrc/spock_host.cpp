@@ -285,7 +285,11 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
         // (crown: 512 threads for the scalar level kernels, whose barriers are cheaper then; 1024 = 16 waves for the MFMA levels,
         //  which have 5 / 9 row tiles of work items per level, times the shares of the node tiles)
         const bool mfma_lv = (nx == 64 && nu == 16 && d == 2) && !std::getenv("SPOCK_AMD_NO_MFMA");
-        for (int thr = ((mode == MODE_CROWN && !mfma_lv) ? 512 : 1024); thr >= 256 && !g.team_local; thr /= 2) {
+        // (many workgroups in flight -- a batch of closed-loop simulations: 512-thread workgroups pack the CUs better than one-round
+        //  1024-thread ones.  Measured, config 4, 64 simulations x 6 steps: 501 -> 455 ms; 8 simulations 133 -> 138 ms, one
+        //  instance 103 -> 119 us per iteration, hence only from two workgroups per CU on)
+        const bool many_wgs = wgs >= 512 && !mfma_lv;
+        for (int thr = (((mode == MODE_CROWN && !mfma_lv) || many_wgs) ? 512 : 1024); thr >= 256 && !g.team_local; thr /= 2) {
             if (const char *e = std::getenv("SPOCK_AMD_TL_THREADS")) thr = std::atoi(e);
             const int nteams = thr / g.team;
             const long scr = (long)nteams * ((dm.ny + 2 * d) + nu + (2 + 2 * d) * g.team);
