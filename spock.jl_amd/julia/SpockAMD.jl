@@ -177,3 +177,13 @@ function reset!(model::GPU_SPOCK)
     gpu_check(ccall((:spock_reset, libspock_amd), Cint, (Ptr{Cvoid},), model.handle))
     gpu_fetch_state!(model)
 end
+
+"""New dynamics of the same shape (e.g. a model re-linearised between the steps of a closed loop): ricatti_offline
+(implicit_l.jl:46-97) and the sweep matrices are recomputed on the GPU in the model's matrix pool (spock_update_dynamics); costs,
+risk measures, constraints and the solver state are kept.  `dynamics.A[w]`, `dynamics.B[w]` as in src/dynamics.jl:1-4."""
+function update_dynamics!(model::GPU_SPOCK, dynamics::Dynamics)
+    A = Vector{Float64}(vcat((vec(Matrix{Float64}(a)) for a in dynamics.A)...))     # [d][nx*nx], column-major per event
+    B = Vector{Float64}(vcat((vec(Matrix{Float64}(b)) for b in dynamics.B)...))     # [d][nx*nu]
+    GC.@preserve A B gpu_check(ccall((:spock_update_dynamics, libspock_amd), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), model.handle, A, B))
+    return nothing
+end
