@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SPOCK_AMD_VERSION 200 /* round 2: spock_options_t.batch_layout, spock_sizes_t.interleaved */
+#define SPOCK_AMD_VERSION 300 /* round 3: spock_abi_struct_sizes, spock_sizes_t.layout_reason, element-major SP */
 
 /* status codes */
 #define SPOCK_OK 0
@@ -126,6 +126,9 @@ typedef struct {
     int32_t split_stage, n_subtrees, graph_iters;
     int32_t fused_iteration;  /* 1: a CP iteration runs as CROWN + SUB_BA (a deterministic rule on the shape), 0: SUB_A + CROWN + SUB_B / whole-tree kernel */
     int32_t interleaved;      /* 1: the batch is held element-major (spock_options_t.batch_layout) */
+    int32_t layout_reason;    /* why `interleaved` is what it is: 0 requested / chosen by the batch-size rule; 1 element-major does not exist for
+                               * this algorithm / shape / per-node data; 2 fell back to instance-major: an array would pass the 4 GiB of the
+                               * kernels' 32-bit buffer offsets (batch too large); 3 fell back: subtree does not fit the LDS slots */
 } spock_sizes_t;
 
 /* build_model(scen_tree, cost, dynamics, rms, constraints, SolverOptions(alg, nothing))
@@ -203,6 +206,10 @@ int spock_debug_stamps(spock_handle_t h, uint64_t *out);
 
 const char *spock_last_error(void);
 int spock_version(void);
+/* sizeof of the four ABI structs as this library was compiled: out[0..3] = spock_problem_t, spock_options_t, spock_result_t,
+ * spock_sizes_t (as many as `cap` allows).  A binding asserts them against its own mirrors when it loads the library, so that a
+ * stale mirror fails loudly instead of making spock_create read past a struct (no reference counterpart: Julia has no FFI here). */
+int spock_abi_struct_sizes(int32_t *out, int32_t cap);
 /* bytes of the device path's arithmetic / storage type: 8 in libspock_amd.so (the reference is Float64 only, src/model.jl:304-307),
  * 4 in libspock_amd_f32.so, the same sources built in single precision for BASELINE config 5's tolerance study.  The ABI is
  * double in both; control blocks, residual reductions and the build step stay double. */

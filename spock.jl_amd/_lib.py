@@ -45,7 +45,7 @@ class Sizes(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
                 ("n", "n_nonleaf", "n_leaf", "nz", "nv", "batch", "z_x", "z_u", "z_s", "z_tau", "z_y",
                  "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v11", "v12", "v13", "v14",
-                 "split_stage", "n_subtrees", "graph_iters", "fused_iteration", "interleaved")]
+                 "split_stage", "n_subtrees", "graph_iters", "fused_iteration", "interleaved", "layout_reason")]
 
 
 # every symbol include/spock_amd.h declares: (restype, argtypes)
@@ -77,6 +77,7 @@ SYMBOLS = {
     "spock_last_error": (C.c_char_p, []),
     "spock_version": (C.c_int, []),
     "spock_real_size": (C.c_int, []),
+    "spock_abi_struct_sizes": (C.c_int, [C.POINTER(_I), _I]),
 }
 
 _cache = {}
@@ -96,6 +97,12 @@ def load_library(path: str | None = None) -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # the mirrors above against the library's own structs: a stale mirror must fail here, not inside spock_create
+    sz = (_I * 4)()
+    lib.spock_abi_struct_sizes(sz, 4)
+    mine = [C.sizeof(Problem), C.sizeof(Options), C.sizeof(Result), C.sizeof(Sizes)]
+    if list(sz) != mine:
+        raise ImportError(f"{path}: ABI struct sizes {list(sz)} differ from this binding's {mine} (rebuild the library)")
     _cache[path] = lib
     return lib
 

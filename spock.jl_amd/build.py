@@ -52,9 +52,10 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, tm
     os.makedirs(tmp, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable", "-Wno-cuda-compat"]
     flags += os.environ.get("SPOCK_BUILD_DEFS", "").split()      # experiment builds (tools/): extra -D... flags
+    kernel_only = os.environ.get("SPOCK_BUILD_KERNEL_FLAGS", "").split()   # flags for the kernel translation units (*.hip) alone
     def compile_one(s):
         o = os.path.join(tmp, s + ".o")
-        cmd = [_hipcc()] + flags + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [_hipcc()] + flags + (kernel_only if s.endswith(".hip") else []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         # recompile only what changed
@@ -81,16 +82,21 @@ def build_f32(force: bool = False, verbose: bool = False) -> str:
     literals in the kernel translation units; compile-time shapes narrowed to the benchmark's (the run-time-dimension kernels
     cover everything else).  Same C ABI (double at the boundary)."""
     global OUT
-    keep, keep_defs = OUT, os.environ.get("SPOCK_BUILD_DEFS")
-    os.environ["SPOCK_BUILD_DEFS"] = "-DSPOCK_REAL=float -cl-single-precision-constant -DSPOCK_STATIC_SHAPES(X)=X(5,2,2,5)X(5,5,2,5)"
+    keep, keep_defs, keep_k = OUT, os.environ.get("SPOCK_BUILD_DEFS"), os.environ.get("SPOCK_BUILD_KERNEL_FLAGS")
+    os.environ["SPOCK_BUILD_DEFS"] = "-DSPOCK_REAL=float -DSPOCK_STATIC_SHAPES(X)=X(5,2,2,5)X(5,5,2,5)"
+    # single-precision literals in the KERNEL translation units only: the host build step (Riccati, eigen-decompositions, the step-size
+    # defaults 0.99 / 3.28 / 10.0 and their thresholds in spock_host.cpp / spock_abi.cpp) stays double, so that the fp32 study
+    # perturbs the device arithmetic and nothing else
+    os.environ["SPOCK_BUILD_KERNEL_FLAGS"] = "-cl-single-precision-constant"
     try:
         return build(force=force, verbose=verbose, out=OUT_F32, tmp_name="build_f32")
     finally:
         OUT = keep
-        if keep_defs is None:
-            os.environ.pop("SPOCK_BUILD_DEFS", None)
-        else:
-            os.environ["SPOCK_BUILD_DEFS"] = keep_defs
+        for k, v in (("SPOCK_BUILD_DEFS", keep_defs), ("SPOCK_BUILD_KERNEL_FLAGS", keep_k)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 if __name__ == "__main__":

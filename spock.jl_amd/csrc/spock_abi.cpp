@@ -50,6 +50,7 @@ struct spock_handle_s {
     // element-major batched regime (spock_igroup.hpp): the iterate as [element][bp]; d_z / d_v then serve as instance-major
     // staging buffers of the API (get / set state)
     bool ilv = false;
+    int layout_reason = 0;   // spock_sizes_t.layout_reason
     long bpad = 0;   // batch rounded up to a multiple of 64
     real *i_z[3] = {nullptr, nullptr, nullptr}, *i_v[2] = {nullptr, nullptr}, *i_cq = nullptr;
     bool stage_valid = false;   // d_z[0] / d_v[0] hold the instance-major copy of the current state
@@ -500,6 +501,12 @@ extern "C" {
 const char *spock_last_error(void) { return g_err.c_str(); }
 int spock_version(void) { return SPOCK_AMD_VERSION; }
 int spock_real_size(void) { return (int)sizeof(real); }
+int spock_abi_struct_sizes(int32_t *out, int32_t cap) {
+    if (!out || cap < 1) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    const int32_t sz[4] = {(int32_t)sizeof(spock_problem_t), (int32_t)sizeof(spock_options_t), (int32_t)sizeof(spock_result_t), (int32_t)sizeof(spock_sizes_t)};
+    for (int k = 0; k < 4 && k < cap; ++k) out[k] = sz[k];
+    return SPOCK_OK;
+}
 
 int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handle_t *out) {
     if (!p || !out) return fail(SPOCK_ERR_BAD_ARG, "problem and out must not be NULL");
@@ -584,6 +591,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     const bool ilv_possible = alg == SPOCK_ALG_CP && N >= 3 && have_static_variant(nx, nu, d, ny) && hp.nQ == 1 && hp.nR == 1 && hp.nQN == 1 && hp.n_rms == 1;
     if (layout == 2 && !ilv_possible) { delete h; return fail(SPOCK_ERR_UNSUPPORTED, "the element-major batch layout exists for CP, the compile-time shapes and shared cost matrices"); }
     bool want_ilv = ilv_possible && (layout == 2 || (layout == 0 && h->batch >= 320));
+    if (!ilv_possible && layout != 1 && h->batch >= 320) h->layout_reason = 1;
 
     bool unsupported = false;
     std::string msg;
@@ -597,7 +605,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
         const bool fits = small && isplit >= 1 && isplit <= N - 2 && (stream_lv || (long)group_threads(d, N - isplit) * nx * 64 * 8 <= 56 * 1024);
         msg = fits ? host_build(hp, isplit, h->bp, unsupported, h->batch) : std::string("subtree does not fit the element-major kernels' LDS slots");
         if (!msg.empty() && layout == 2) { delete h; return fail(SPOCK_ERR_UNSUPPORTED, msg); }
-        if (!msg.empty()) want_ilv = false;   // chosen automatically: fall back to the instance-major kernels
+        if (!msg.empty()) { want_ilv = false; h->layout_reason = small ? 3 : 2; }   // chosen automatically: fall back to the instance-major kernels, and say so
     }
     if (!want_ilv) msg = host_build(hp, split, h->bp, unsupported, h->batch);
     if (!msg.empty()) { delete h; return fail(unsupported ? SPOCK_ERR_UNSUPPORTED : SPOCK_ERR_BUILD, msg); }
@@ -708,6 +716,7 @@ int spock_sizes(spock_handle_t h, spock_sizes_t *s) {
     s->split_stage = dm.t0; s->n_subtrees = dm.nsub; s->graph_iters = h->graph_iters;
     s->fused_iteration = h->fused ? 1 : 0;
     s->interleaved = h->ilv ? 1 : 0;
+    s->layout_reason = h->layout_reason;
     return SPOCK_OK;
 }
 
@@ -1025,28 +1034,41 @@ int spock_update_dynamics(spock_handle_t h, const double *A, const double *B) {
     const size_t na = (size_t)dm.d * dm.nx * dm.nx, nb = (size_t)dm.d * dm.nx * dm.nu;
     for (size_t k = 0; k < na; ++k) if (!std::isfinite(A[k])) return fail(SPOCK_ERR_BAD_ARG, "A must be finite");
     for (size_t k = 0; k < nb; ++k) if (!std::isfinite(B[k])) return fail(SPOCK_ERR_BAD_ARG, "B must be finite");
-    void *dA = nullptr, *dB = nullptr, *dws = nullptr, *dst = nullptr;
+    // The kernel rewrites the dynamics-dependent regions of the LIVE pool in place (A, B, K, Rtilde^-1, P, ABK, U / W / V, the sweep
+    // blocks).  A failed build (Rtilde not positive definite) must leave the handle as it was: snapshot the pool (it is small --
+    // stage-shared matrices), restore it on failure, and touch the host-side copies only on success.
+    void *dA = nullptr, *dB = nullptr, *dws = nullptr, *dst = nullptr, *dsnap = nullptr;
+    const size_t pool_bytes = h->bp.mats.size() * sizeof(real);
     int e = rt::dmalloc(&dA, na * sizeof(double));
     if (!e) e = rt::dmalloc(&dB, nb * sizeof(double));
     if (!e) e = rt::dmalloc(&dws, (size_t)build_ws_doubles(dm) * sizeof(double));
     if (!e) e = rt::dmalloc(&dst, sizeof(int));
+    if (!e) e = rt::dmalloc(&dsnap, pool_bytes);
     int status = 0;
+    if (!e) e = rt::d2d(dsnap, h->d_mats, pool_bytes, h->stream);
     if (!e) e = rt::h2d(dA, A, na * sizeof(double), h->stream);
     if (!e) e = rt::h2d(dB, B, nb * sizeof(double), h->stream);
+    bool launched = false;
     if (!e) {
         BuildArgs a;
         a.dm = dm; a.mats = h->d_mats; a.A = (const double *)dA; a.B = (const double *)dB; a.ws = (double *)dws; a.status = (int *)dst;
         e = launch_build_riccati(a, h->stream);
+        launched = true;
     }
     if (!e) e = rt::d2h(&status, dst, sizeof(int), h->stream);
     if (!e) e = rt::sync(h->stream);
-    for (void *q : {dA, dB, dws, dst}) if (q) rt::dfree(q);
+    if (launched && (e || status != 0)) {   // roll back: the pool is again the one of the last successful build
+        int e2 = rt::d2d(h->d_mats, dsnap, pool_bytes, h->stream);
+        if (!e2) e2 = rt::sync(h->stream);
+        if (e2 && !e) e = e2;
+    }
+    for (void *q : {dA, dB, dws, dst, dsnap}) if (q) rt::dfree(q);
     if (e) return fail(SPOCK_ERR_HIP, std::string("spock_update_dynamics: ") + rt::err(e));
+    if (status != 0) return fail(SPOCK_ERR_BUILD, "Rtilde is not positive definite (the model keeps its previous dynamics)");
     h->hp.A.assign(A, A + na); h->hp.B.assign(B, B + nb);
     h->dyn_on_device = true;
     if (h->graph) { rt::graph_destroy(h->graph); h->graph = nullptr; }        // (the captured launches carry no pool contents, but stay on the safe side)
     if (h->graph_log) { rt::graph_destroy(h->graph_log); h->graph_log = nullptr; }
-    if (status != 0) return fail(SPOCK_ERR_BUILD, "Rtilde is not positive definite");
     return SPOCK_OK;
 }
 

@@ -82,7 +82,9 @@ static int launch_ivariant(int mode, const KArgs &a_in, hipStream_t st) {
 __global__ void __launch_bounds__(256) spock_transpose_kernel(real *__restrict__ dst, const real *__restrict__ src, long rows, long cols,
                                                               long ld_src, long ld_dst) {
     __shared__ real tile[32][33];
-    const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+    // one-dimensional grid (block = column tile + row tile * column tiles): nz / 32 row tiles pass grid.y's 65535 from nz ~ 2.1 M on
+    const long nbx = (cols + 31) / 32;
+    const long r0 = ((long)blockIdx.x / nbx) * 32, c0 = ((long)blockIdx.x % nbx) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int k = ty; k < 32; k += 8) {
         const long r = r0 + k, c = c0 + tx;
@@ -97,7 +99,9 @@ __global__ void __launch_bounds__(256) spock_transpose_kernel(real *__restrict__
 
 int launch_transpose(real *dst, const real *src, long rows, long cols, long ld_src, long ld_dst, void *stream) {
     if (rows <= 0 || cols <= 0) return 0;
-    const dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    const long nblk = ((cols + 31) / 32) * ((rows + 31) / 32);
+    if (nblk > 0x7fffffffL) return (int)hipErrorInvalidConfiguration;
+    const dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL(spock_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, dst, src, rows, cols, ld_src, ld_dst);
     return (int)hipGetLastError();
 }

@@ -29,6 +29,7 @@ struct SpockProblemC           # spock_problem_t (include/spock_amd.h)
     E::Ptr{Cdouble}; F::Ptr{Cdouble}; b::Ptr{Cdouble}
     n_cones::Cint; cone_kind::Ptr{Cint}; cone_dim::Ptr{Cint}
     x_min::Cdouble; x_max::Cdouble; u_min::Cdouble; u_max::Cdouble
+    n_rms::Cint                # 1: E, F, b hold one risk measure; n_nonleaf: one (ny x d), (ny x d), (ny) block per non-leaf node
 end
 
 struct SpockOptionsC           # spock_options_t
@@ -42,11 +43,11 @@ struct SpockResultC            # spock_result_t
     xi1::Cdouble; xi2::Cdouble; xi::Cdouble; solve_ms::Cdouble
 end
 
-struct SpockSizesC             # spock_sizes_t: 27 x int32
+struct SpockSizesC             # spock_sizes_t: 28 x int32
     n::Cint; n_nonleaf::Cint; n_leaf::Cint; nz::Cint; nv::Cint; batch::Cint
     z_x::Cint; z_u::Cint; z_s::Cint; z_tau::Cint; z_y::Cint
     v1::Cint; v2::Cint; v3::Cint; v4::Cint; v5::Cint; v6::Cint; v7::Cint; v11::Cint; v12::Cint; v13::Cint; v14::Cint
-    split_stage::Cint; n_subtrees::Cint; graph_iters::Cint; fused_iteration::Cint; interleaved::Cint
+    split_stage::Cint; n_subtrees::Cint; graph_iters::Cint; fused_iteration::Cint; interleaved::Cint; layout_reason::Cint
 end
 
 # what scripts read: model.solver_state.z / .v (mpc_simulation.jl:50-54); batch > 1: [nz, batch] column per instance
@@ -70,6 +71,15 @@ mutable struct GPU_SPOCK <: CUSTOM_SOLVER_MODEL
     results::Vector{SpockResultC}
 end
 
+# The C structs above must match include/spock_amd.h field for field (tests/test_abi_layout.py parses both files); the
+# library reports its own sizes so that a stale binding fails at load instead of reading past a struct.
+function gpu_check_layout()
+    sz = zeros(Cint, 4)
+    ccall((:spock_abi_struct_sizes, libspock_amd), Cint, (Ptr{Cint}, Cint), sz, 4)
+    (sz[1] == sizeof(SpockProblemC) && sz[2] == sizeof(SpockOptionsC) && sz[3] == sizeof(SpockResultC) && sz[4] == sizeof(SpockSizesC)) ||
+        error("SpockAMD.jl does not match libspock_amd.so: struct sizes $(sz) vs $(sizeof.((SpockProblemC, SpockOptionsC, SpockResultC, SpockSizesC)))")
+end
+
 gpu_check(rc) = rc == 0 || error(unsafe_string(ccall((:spock_last_error, libspock_amd), Cstring, ())))
 
 # ConvexBaseCone kinds (src/risk_measures.jl:6) -> SPOCK_CONE_* (spock_amd.h)
@@ -91,17 +101,30 @@ function build_model(scen_tree::AbstractScenarioTree, cost::AbstractCost, dynami
     B = Vector{Float64}(vcat((vec(Matrix(b)) for b in dynamics.B)...))
     anc = Cint[i == 1 ? -1 : scen_tree.anc_mapping[i] - 1 for i in 1:n]        # scenario_tree.jl:90-95, 0-based
     w = Cint[i == 1 ? -1 : scen_tree.node_info[i].w - 1 for i in 1:n]          # scenario_tree.jl:77, 0-based event
-    rm = rms[1]                                                                # uniform risk measures (implicit_l.jl:14,19)
-    all(r -> r.E == rm.E && r.F == rm.F && r.b == rm.b, rms) || error("non-uniform risk measures: not supported on the GPU path")
-    E = Vector{Float64}(vec(rm.E)); F = Vector{Float64}(vec(rm.F)); b = Vector{Float64}(rm.b)
+    # risk measures: one per non-leaf node (src/risk_measures.jl:93-102 uniform, :127-136 one AV@R per node).  length(b) and the
+    # cone K are common to all of them (implicit_l.jl:14,19); identical measures are passed once (n_rms = 1), else stacked
+    # node by node: E, F as (ny x d) column-major blocks, b as ny-blocks
+    rm = rms[1]
+    ny = length(rm.b)
+    all(r -> length(r.b) == ny && size(r.E) == size(rm.E) && size(r.F) == size(rm.F), rms) ||
+        error("risk measures with differing length(b): not supported on the GPU path")
     kinds = Cint[gpu_cone_kind(c) for c in rm.K.subcones]
     dims = Cint[MOI.dimension(c) for c in rm.K.subcones]
+    all(r -> Cint[gpu_cone_kind(c) for c in r.K.subcones] == kinds && Cint[MOI.dimension(c) for c in r.K.subcones] == dims, rms) ||
+        error("risk measures with differing cones: not supported on the GPU path")
+    uniform_rms = all(r -> r.E == rm.E && r.F == rm.F && r.b == rm.b, rms)
+    n_rms = uniform_rms ? 1 : length(rms)                                      # length(rms) == number of non-leaf nodes
+    src = uniform_rms ? [rm] : rms
+    E = Vector{Float64}(vcat((vec(Matrix{Float64}(r.E)) for r in src)...))
+    F = Vector{Float64}(vcat((vec(Matrix{Float64}(r.F)) for r in src)...))
+    b = Vector{Float64}(vcat((Vector{Float64}(r.b) for r in src)...))
     h = Ref{Ptr{Cvoid}}(C_NULL)
+    gpu_check_layout()
     GC.@preserve anc w A B Q R QN E F b kinds dims begin
-        p = SpockProblemC(scen_tree.N, d, nx, nu, length(b), pointer(anc), pointer(w), pointer(A), pointer(B),
+        p = SpockProblemC(scen_tree.N, d, nx, nu, ny, pointer(anc), pointer(w), pointer(A), pointer(B),
                           nQ, nR, nQN, pointer(Q), pointer(R), pointer(QN), pointer(E), pointer(F), pointer(b),
                           length(kinds), pointer(kinds), pointer(dims),
-                          constraints.x_min, constraints.x_max, constraints.u_min, constraints.u_max)
+                          constraints.x_min, constraints.x_max, constraints.u_min, constraints.u_max, Cint(n_rms))
         o = SpockOptionsC(Int(solver_options.algorithm), gpu.device, gpu.batch, 0, gpu.L_norm, 0, 0, 0, 0, 0, 0)   # sp_variant 0: as the reference
         gpu_check(ccall((:spock_create, libspock_amd), Cint, (Ref{SpockProblemC}, Ref{SpockOptionsC}, Ref{Ptr{Cvoid}}), p, o, h))
     end

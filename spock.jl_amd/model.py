@@ -194,7 +194,8 @@ class Model:
         if len(dynamics.A) != fl.d or len(dynamics.B) != fl.d:
             raise ValueError("the new dynamics must have the shape of the old ones")
         A = _stack_colmajor(dynamics.A, fl.nx, fl.nx); B = _stack_colmajor(dynamics.B, fl.nx, fl.nu)
-        _lib.check(self._lib, self._lib.spock_update_dynamics(self._h, _ptr(A), _ptr(B)))
+        _lib.check(self._lib, self._lib.spock_update_dynamics(self._h, _ptr(A), _ptr(B)))   # raises on failure: the model then keeps its dynamics
+        fl.A, fl.B = A, B
 
     MODE_NAMES = {0: "full", 1: "sub_a", 2: "crown", 3: "sub_b", 5: "sub_ba", 8: "sub_b_lat", 9: "crown_a", 10: "i_up", 11: "i_down",
                   12: "lb", 13: "lba", 14: "la", 15: "la0"}

@@ -32,7 +32,7 @@ def test_library_exports_every_symbol(S, built):
     lib = S.load_library()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.spock_version() == 200 and lib.spock_real_size() == 8
+    assert lib.spock_version() == 300 and lib.spock_real_size() == 8
     # the fp32 variant: same sources, same C ABI, real = float
     from spock_jl_amd import _lib
     lib32 = S.load_library(_lib.F32_LIB)
