@@ -18,11 +18,19 @@ inputs are resident in HBM before the timed region (a step uploads only the nx-d
     value = n_gpus * batch * iters * steps / time      ("Spock iterations per second", whole job, weak scaling)
 
 The JSON line also carries
-  roofline        the dominant kernel: algorithmic bytes per launch / its average HIP-event duration,
-                  measured live after the timed region on the stream the kernels run on; `necessary_bytes_per_launch` is
-                  the entry-by-entry count of what that kernel must move, `frac_necessary` the fraction of the HBM peak on it;
-                  `traffic` = PMC bytes of the same kernel from the committed rocprofv3 pass of the SAME library build
-                  (null when the pass is of another build)
+  roofline        the dominant kernel (the bottom-stage level kernel LBA): `bytes_per_launch` = the entry-by-entry count of what that
+                  kernel must move (`bytes_model` says which count), `avg_launch_ms` its average HIP-event duration measured live
+                  after the timed region on the stream the kernels run on, `achieved` / `frac` = that rate against the 8 TB/s HBM peak;
+                  `traffic` (`traffic_raw`) = PMC bytes of the same kernel per launch from the committed rocprofv3 passes of the SAME
+                  library build (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; null when the committed pass is of
+                  another build), `frac_measured` the rate on them; `survey_8d_*` = SURVEY.md 8(d)'s stream model of an unfused
+                  implementation, kept beside it (on that model a fused kernel "exceeds" the peak: it counts bytes nobody moves).
+                  Whole iteration: `whole_iteration_necessary_bytes` / `whole_iteration_frac` (necessary bytes over the timed
+                  region's time per iteration), `traffic_iteration` = PMC bytes of ALL launches of one iteration,
+                  `frac_iteration_measured` = those over the same time, `waste_ratio` = traffic_iteration / necessary bytes
+                  (re-reads the level structure adds).  tools/pmc_summary.py recomputes all of it from profiles/<round>/*.csv
+  parity          after the timed region: the first instance, one of a middle tile and the last one of the batch against the CPU
+                  oracle run for the same iterations (per-block relative error of z and v); `parity_max_relerr` is the largest
   cpu_baseline    the CPU oracle (single-thread C restatement of the reference) on ONE instance of the same workload, on
                   this box's host cores (rank 0, N=1 only), plus the same with one oracle process per host core
   single_instance latency-bound regime (N=1 only)
@@ -57,6 +65,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
     ap.add_argument("--no-mpc", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle self-check of the headline state (profiling runs)")
+    ap.add_argument("--parity-max-iters", type=int, default=4000, help=argparse.SUPPRESS)
     ap.add_argument("--mpc-per-gpu", type=int, default=8)
     ap.add_argument("--mpc-total", type=int, default=64)
     # test hooks (tests/test_bench_contract.py drives the whole N = 2 path on CPUs with the emulation library)
@@ -113,6 +123,24 @@ def lba_necessary_bytes(flat):
     writes = (2 * nxu + nu) + (2 * ny + 1 + 2 * d) + d * (nxu + 2) + d * (3 * nx + 2)
     n_bottom = flat.nl // d
     return W * n_bottom * (reads + writes)
+
+
+def block_relerr(flat, which, a, b):
+    """Largest per-block relative error of a z- or v-shaped vector against the oracle's (blocks x|u|s|tau|y, v1..v14; a block's
+    scale floored at 1e-3 of max(1, |b|_inf) -- the measure of tests/conftest.py)."""
+    import numpy as np
+    if which == "z":
+        blocks = [(sl.start, sl.stop) for sl in flat.z_slices().values()]
+    else:
+        off = flat.v_offsets(); names = ["v1", "v2", "v3", "v4", "v5", "v6", "v7", "v11", "v12", "v13", "v14", "end"]
+        blocks = [(off[names[i]], off[names[i + 1]]) for i in range(len(names) - 1)]
+    g = max(1.0, float(np.max(np.abs(b))))
+    worst = 0.0
+    for lo, hi in blocks:
+        if hi > lo:
+            e = float(np.max(np.abs(a[lo:hi] - b[lo:hi]))) / max(float(np.max(np.abs(b[lo:hi]))), 1e-3 * g)
+            worst = e if (e > worst or e != e) else worst
+    return worst
 
 
 def lib_fingerprint(path):
@@ -206,6 +234,33 @@ def main(argv=None):
         rec = sdist.gather_records(sdist.instance_record(model, res, NU), [B] * world, device=tdev)
         assert rec.shape == (B * world, NU + 5)
     value = n_gpus * B * M * args.steps / elapsed
+    layout_ok = bool(getattr(model.sizes, "interleaved", 0)) or B < 320
+    assert layout_ok, f"batch {B}: the element-major regime was not selected (layout_reason {getattr(model.sizes, 'layout_reason', '?')}): the roofline labels below describe its kernels"
+
+    # ---- self-check of the headline: three instances of the state the timed region left behind against the CPU oracle run for the
+    #      same iterations (warm-up + timed steps, each a solve of M iterations warm-started from the last).  Outside the timed region.
+    parity = None
+    if rank == 0 and not args.no_parity:
+        from oracle import oracle as O
+        total_steps = args.warmup + args.steps
+        fresh = total_steps * M > args.parity_max_iters      # too long for the oracle: check one fresh step instead
+        if fresh:
+            model.reset(); step(); total_steps = 1
+        Z, V = model.solver_state.z.reshape(B, -1), model.solver_state.v.reshape(B, -1)
+        picks = sorted(set([0, (B // 128) * 64 + min(37, B - 1) if B >= 128 else B // 2, B - 1]))
+        worst = 0.0
+        t = time.perf_counter()
+        for b in picks:
+            o = O.Oracle(flat, O.CP)
+            for _ in range(total_steps):
+                o.solve(x0[b], tol=0.0, max_iter=M)
+            e = max(block_relerr(flat, "z", Z[b], o.z), block_relerr(flat, "v", V[b], o.v))
+            worst = e if (e > worst or e != e) else worst
+        parity = {"instances": picks, "iterations_compared": total_steps * M,
+                  "state": "one fresh step after the timed region" if fresh else "the state left by warm-up + timed steps",
+                  "measure": "per-block relative error of z and v against the CPU oracle (blocks x|u|s|tau|y, v1..v14)",
+                  "max_relerr": worst, "oracle_s": round(time.perf_counter() - t, 2)}
+        assert worst <= 1e-8, f"headline state differs from the oracle: {parity}"
 
     # ---- roofline of the dominant kernel: HIP events around every launch, same workload, same stream
     roofline = None
@@ -226,13 +281,13 @@ def main(argv=None):
         traffic = traffic_raw = None
         fp = lib_fingerprint(args.lib or slib.DEFAULT_LIB)
         pdir = os.path.join(ROOT, "profiles")
-        pmc_kernels = {}
+        pmc_kernels, pmc_iter, pmc_file = {}, None, None
         for rnd in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
             f = os.path.join(pdir, rnd, f"pmc_b{B}_summary.json")
             if os.path.exists(f):
                 summ = json.load(open(f))
                 if summ.get("lib_sha16") == fp:
-                    pmc_kernels = summ.get("kernels", {})
+                    pmc_kernels = summ.get("kernels", {}); pmc_iter = summ.get("iteration"); pmc_file = os.path.relpath(f, ROOT)
                 break
         k = pmc_kernels.get("sub_ba" if (fused and dom == "sub_b") else dom)
         if k:
@@ -270,6 +325,16 @@ def main(argv=None):
                     "iteration_launches_ms": [[n, lv, round(ms, 5)] for (n, lv, ms) in seq],
                     "whole_iteration_necessary_bytes": B * necessary_bytes(flat),
                     "whole_iteration_frac": round(B * necessary_bytes(flat) * n_gpus / (elapsed / (M * args.steps)) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4)}
+        # the whole iteration on the counters: PMC bytes of every launch of one iteration (profiles/<round>/pmc_b<B>_summary.json,
+        # written by tools/pmc_summary.py from the committed CSVs) over the timed region's time per iteration
+        it_s = elapsed / (M * args.steps)
+        tr_it = pmc_iter["hbm_bytes_corrected"] if pmc_iter else None
+        roofline.update({"traffic_iteration": tr_it, "traffic_iteration_raw": pmc_iter["hbm_bytes_raw"] if pmc_iter else None,
+                         "frac_iteration_measured": round(tr_it / it_s / 1e9 / HBM_PEAK_GBS, 4) if tr_it else None,
+                         "waste_ratio": round(tr_it / (B * necessary_bytes(flat)), 4) if tr_it else None,
+                         "iteration_ms": round(it_s * 1e3, 5), "pmc_summary": pmc_file,
+                         "survey_8d_iteration_bytes": B * bytes_["cp_iteration"],
+                         "survey_8d_iteration_rate_GBps": round(B * bytes_["cp_iteration"] / it_s / 1e9, 1)})
     model.close()
 
     out = {"metric": "Spock (Chambolle-Pock) iterations/sec on the server_heat tree", "value": round(value, 1),
@@ -281,6 +346,9 @@ def main(argv=None):
                       "split_stage": int(model.sizes.split_stage), "algorithm": "CP", "fused_iteration": fused,
                       "parallelism": f"{n_gpus} x {B} independent instances, RCCL all_gather of results only"},
            "roofline": roofline}
+    if parity is not None:
+        out["parity"] = parity
+        out["parity_max_relerr"] = parity["max_relerr"]
 
     # ---- BASELINE config 4: closed-loop MPC simulations sharded over the ranks (the metric's problems/sec leg)
     if not args.no_mpc:

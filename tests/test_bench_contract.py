@@ -51,6 +51,8 @@ def test_bench_runs_n_ranks_and_prints_one_line(gpus):
     out = json.loads(lines[0])
     _check_contract(out)
     assert out["n_gpus"] == gpus and out["config"]["instances_per_gpu"] == 2
+    # the headline checks itself: instances of the timed state against the oracle, per-block relative error
+    assert out["parity"]["iterations_compared"] == 6 and out["parity_max_relerr"] <= 1e-9 and out["parity"]["instances"] == [0, 1]
     mpc = out["mpc_cfg4"]
     assert mpc["weak"]["simulations"] == 2 * gpus and mpc["strong"]["simulations"] == 5
     assert sum(mpc["strong"]["per_gpu"]) == 5 and len(mpc["strong"]["per_gpu"]) == gpus

@@ -507,6 +507,18 @@ def test_emulated_build_step_on_the_device(S, O, emu):
     bad = dataclasses.replace(dyn, A=[np.full_like(a, np.nan) for a in dyn.A])
     with pytest.raises(S.SpockError):
         m.update_dynamics(bad)
+    # a build that FAILS on the device (finite dynamics whose Riccati recursion overflows: Rtilde is then not positive definite)
+    # must leave the model as it was -- the kernel rewrites the live pool in place, the driver restores its snapshot
+    m.reset()
+    S.solve_model(m, x0, tol=1e-6); z_before = m.solver_state.z.copy(); P_before = m.build_product(0)
+    A_before = m.problem_definition.A.copy()
+    boom = dataclasses.replace(dyn, A=[1e160 * np.eye(5) for _ in dyn.A])
+    with pytest.raises(S.SpockError) as err:
+        m.update_dynamics(boom)
+    assert err.value.code == 4 and "previous dynamics" in str(err.value)
+    assert np.array_equal(m.problem_definition.A, A_before) and np.array_equal(m.build_product(0), P_before)
+    m.reset(); S.solve_model(m, x0, tol=1e-6)
+    assert np.array_equal(m.solver_state.z, z_before)
     m.close(); ref.close()
 
 

@@ -480,7 +480,39 @@ def test_build_step_on_the_device(S, O, N, nx):
     m.reset(); ref.reset()
     xa, ua, _ = S.mpc_simulation(m, x0, w, tol=1e-3); xb, ub, _ = S.mpc_simulation(ref, x0, w, tol=1e-3)
     assert np.max(np.abs(xa - xb)) <= 1e-9 and np.max(np.abs(ua - ub)) <= 1e-9
+    # a failing device build (the Riccati recursion overflows) leaves the model as it was: pool restored from the snapshot
+    m.reset()
+    S.solve_model(m, x0, tol=1e-9); z_before = m.solver_state.z.copy(); P_before = m.build_product(0)
+    boom = dataclasses.replace(dyn, A=[1e160 * np.eye(nx) for _ in dyn.A])
+    with pytest.raises(S.SpockError) as err:
+        m.update_dynamics(boom)
+    assert err.value.code == 4
+    assert np.array_equal(m.build_product(0), P_before)
+    m.reset(); S.solve_model(m, x0, tol=1e-9)
+    assert np.array_equal(m.solver_state.z, z_before)
     m.close(); ref.close()
+
+
+def test_interleaved_state_copy_with_many_rows(S, O):
+    """The instance-major <-> element-major copies of the API (launch_transpose) with more than 65535 x 32 rows: nv = 2.8 M at
+    nx = 5, nu = 2, N = 17 (a two-dimensional grid put rows / 32 into grid.y and failed with hipErrorInvalidConfiguration in
+    spock_get_v after a solve that succeeded).  One tile of instances, six CP iterations, two instances against the oracle."""
+    specs = S.get_server_heat_specs(17, 5, 2, nu=2)
+    flat = S.flatten_problem(*specs)
+    assert flat.nv > 65535 * 32
+    B = 64
+    x0 = 0.1 * (1 + 0.01 * np.arange(B))[:, None] * np.ones((B, 5))
+    m = S.build_model(*specs, batch=B, layout="interleaved", max_iter=6)
+    assert m.sizes.interleaved == 1
+    S.solve_model(m, x0, tol=0.0)
+    Z = m.solver_state.z; V = m.solver_state.v
+    for b in (0, 63):
+        o = O.Oracle(flat, O.CP); o.solve(x0[b], tol=0.0, max_iter=6)
+        assert relerr(Z[b], o.z) <= 1e-10 and relerr(V[b], o.v) <= 1e-10
+    # and back: set_state goes through the other direction of the copy
+    m.set_state(Z, V)
+    assert np.array_equal(m.solver_state.z, Z) and np.array_equal(m.solver_state.v, V)
+    m.close()
 
 
 # ---- element-major ("interleaved") batched regime (spock_igroup.hpp): one lane per instance, one wave per tree node -----------
@@ -574,9 +606,9 @@ def test_interleaved_layout_fp32_library(S, O):
 
 
 def test_interleaved_full_size_cfg2(S, O):
-    """BASELINE config 2 at full size in the benchmark's regime (element-major, 3 layers of groups, 4 tile groups on their own
-    streams): 48 CP iterations of 256 instances, three of them against the oracle; NaN input ends one instance with SPOCK_NAN
-    and leaves its tile neighbours untouched."""
+    """BASELINE config 2 at full size, element-major (crown group + level-streaming kernels, one tile group -- the default):
+    48 CP iterations of 256 instances, three of them against the oracle; NaN input ends one instance with SPOCK_NAN and leaves
+    its tile neighbours untouched.  (The benchmark's own 2048-instance regime: test_bench_regime_matches_oracle.)"""
     specs = S.get_server_heat_specs(13, 5, 2, nu=2)
     flat = S.flatten_problem(*specs)
     B = 256
@@ -593,4 +625,27 @@ def test_interleaved_full_size_cfg2(S, O):
     rs = S.solve_model(m, xb, tol=0.0)
     assert rs[70]["status"] == 2 and rs[69]["status"] == 1 and rs[71]["status"] == 1
     assert relerr(m.solver_state.z[69], Z[69]) == 0.0 and relerr(m.solver_state.z[71], Z[71]) == 0.0
+    m.close()
+
+
+def test_bench_regime_matches_oracle(S, O):
+    """The headline benchmark's OWN regime (bench.py defaults): 2048 instances = 32 tiles, element-major, one hipGraph of 96 CP
+    iterations, tol = 0, x0 as bench.py forms it.  The first instance, one of a middle tile and the last one against the oracle
+    run for the same 96 iterations (examples/server_heat/residuals.jl:10-32 protocol: same problem, same iteration count);
+    a second step (warm start from the state left behind, as bench.py's timed loop does) likewise."""
+    specs = S.get_server_heat_specs(13, 5, 2, nu=2)
+    flat = S.flatten_problem(*specs)
+    B, M = 2048, 96
+    x0 = 0.1 * (1.0 + 0.001 * np.arange(B))[:, None] * np.ones((B, 5))
+    m = S.build_model(*specs, batch=B, max_iter=M, graph_iters=M)
+    assert m.sizes.interleaved == 1 and m.sizes.layout_reason == 0 and m.sizes.graph_iters == M
+    picks = (0, 1000, 2047)
+    oracles = {b: O.Oracle(flat, O.CP) for b in picks}
+    for step in range(2):
+        rs = S.solve_model(m, x0, tol=0.0)
+        assert all(r["iterations"] == M and r["status"] == 1 for r in rs)
+        Z, V = m.solver_state.z, m.solver_state.v
+        for b in picks:
+            oracles[b].solve(x0[b], tol=0.0, max_iter=M)
+            assert relerr(Z[b], oracles[b].z) <= 1e-9 and relerr(V[b], oracles[b].v) <= 1e-9, (step, b)
     m.close()

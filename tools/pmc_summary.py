@@ -4,12 +4,19 @@
     pmc_b<B>_summary.json            per kernel: mean FETCH_SIZE / WRITE_SIZE (KB) per launch and HBM bytes per launch,
                                      raw and with FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
 
-    python tools/pmc_summary.py r01 256
+    pmc_b<B>_summary.json also carries "iteration": the launches of ONE CP iteration (every kernel kind that runs once or more per
+    iteration, its launches per iteration = its launch count / the bottom kernel's), their PMC bytes summed -- what bench.py's
+    roofline.traffic_iteration / frac_iteration_measured / waste_ratio are computed from -- and "per_kind_table", one row per
+    kernel kind: launches per iteration, mean duration (from the kernel_stats.csv), bytes per launch, achieved TB/s.
+
+    python tools/pmc_summary.py r03 2048                 condense gpurun_out/prof_r03 into profiles/r03
+    python tools/pmc_summary.py r03 2048 --recompute     recompute the summary from the CSVs already committed under profiles/r03
 """
 import csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd, B = sys.argv[1], int(sys.argv[2])
+RECOMPUTE = "--recompute" in sys.argv[3:]
 src = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -38,17 +45,22 @@ def kind(name):
 
 
 newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)   # gpurun_out/ accumulates earlier runs
-shutil.copy(newest(os.path.join(src, "stats", "**", "*kernel_stats.csv")), os.path.join(dst, f"bench_b{B}_kernel_stats.csv"))
+stats_csv = os.path.join(dst, f"bench_b{B}_kernel_stats.csv")
+if not RECOMPUTE:
+    shutil.copy(newest(os.path.join(src, "stats", "**", "*kernel_stats.csv")), stats_csv)
 import hashlib
 _h = hashlib.sha256(open(os.path.join(ROOT, "spock.jl_amd", "libspock_amd.so"), "rb").read()).hexdigest()[:16]
+if RECOMPUTE and os.path.exists(os.path.join(dst, f"pmc_b{B}_summary.json")):
+    _h = json.load(open(os.path.join(dst, f"pmc_b{B}_summary.json"))).get("lib_sha16", _h)   # the build the committed passes ran
 out = {"config": f"SPOCK_AMD_ILV_TGROUPS=1 bench.py --batch {B} (server_heat nx=5 nu=2 d=2 N=13), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes",
        "kernels": {}, "batch": B, "lib_sha16": _h}
 for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = newest(os.path.join(src, sub, "**", "*counter_collection.csv"))
+    f = os.path.join(dst, f"{sub}_counter_collection.csv") if RECOMPUTE else newest(os.path.join(src, sub, "**", "*counter_collection.csv"))
     rows = list(csv.DictReader(open(f)))
     keep = [r for r in rows if kind(r["Kernel_Name"])]
-    with open(os.path.join(dst, f"{sub}_counter_collection.csv"), "w", newline="") as g:
-        w = csv.DictWriter(g, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep[:400])
+    if not RECOMPUTE:   # every dispatch of the CP kernels is kept: the summary must be recomputable from the committed file
+        with open(os.path.join(dst, f"{sub}_counter_collection.csv"), "w", newline="") as g:
+            w = csv.DictWriter(g, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep)
     acc = {}
     for r in keep:
         if r["Counter_Name"] != ctr:
@@ -61,5 +73,34 @@ for k, e in out["kernels"].items():
     f, w = e.get("FETCH_SIZE_KB_mean", 0.0), e.get("WRITE_SIZE_KB_mean", 0.0)
     e["hbm_bytes_per_launch_raw"] = int((f + w) * 1024)
     e["hbm_bytes_per_launch_corrected"] = int((2 * f + w) * 1024)
+# ---- one iteration: every kind that is launched at least once per iteration of the bottom kernel (lba, or sub_ba / sub_b / full)
+ks = out["kernels"]
+bottom = next((k for k in ("lba", "sub_ba", "sub_b", "full") if k in ks), None)
+dur = {}   # mean duration per kind from the --stats pass (ns -> ms), pooled over the kernel names of a kind
+if os.path.exists(stats_csv):
+    tot, cnt = {}, {}
+    for r in csv.DictReader(open(stats_csv)):
+        k = kind(r["Name"])
+        if k:
+            tot[k] = tot.get(k, 0.0) + float(r["TotalDurationNs"]); cnt[k] = cnt.get(k, 0) + int(r["Calls"])
+    dur = {k: tot[k] / cnt[k] / 1e6 for k in tot}
+if bottom:
+    nb = ks[bottom]["FETCH_SIZE_launches"]
+    per_it, table = {}, []
+    raw = corr = 0.0
+    for k, e in ks.items():
+        lp = e.get("FETCH_SIZE_launches", 0) / nb
+        if lp < 0.99:          # prologue / finalize kernels: not part of an iteration
+            continue
+        lp = round(lp)
+        per_it[k] = lp
+        raw += lp * e["hbm_bytes_per_launch_raw"]; corr += lp * e["hbm_bytes_per_launch_corrected"]
+        ms = dur.get(k)
+        table.append({"kind": k, "launches_per_iteration": lp, "avg_ms": round(ms, 5) if ms else None,
+                      "hbm_bytes_per_launch_corrected": e["hbm_bytes_per_launch_corrected"],
+                      "achieved_TBps": round(e["hbm_bytes_per_launch_corrected"] / (ms * 1e-3) / 1e12, 3) if ms else None})
+    out["iteration"] = {"launches": per_it, "hbm_bytes_raw": int(raw), "hbm_bytes_corrected": int(corr),
+                        "ms_sum_of_launches": round(sum(t["launches_per_iteration"] * t["avg_ms"] for t in table if t["avg_ms"]), 5)}
+    out["per_kind_table"] = sorted(table, key=lambda t: -(t["avg_ms"] or 0) * t["launches_per_iteration"])
 json.dump(out, open(os.path.join(dst, f"pmc_b{B}_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
