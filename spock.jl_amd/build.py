@@ -11,11 +11,12 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["spock_kernels.hip", "spock_ikernels.hip", "spock_lkernels.hip", "spock_bkernels.hip", "spock_abi.cpp", "spock_host.cpp", "spock_rt_hip.cpp"]
-HEADERS = ["spock_device.hpp", "spock_group.hpp", "spock_igroup.hpp", "spock_ilevel.hpp", "spock_build.hpp", "spock_shapes.hpp", "spock_internal.hpp", "spock_rt.hpp", "spock_sp.hpp", "spock_team_local.hpp", os.path.join("..", "..", "include", "spock_amd.h")]
+SOURCES = ["spock_kernels.hip", "spock_fkernels.hip", "spock_ikernels.hip", "spock_lkernels.hip", "spock_bkernels.hip", "spock_abi.cpp", "spock_host.cpp", "spock_rt_hip.cpp"]
+HEADERS = ["spock_flat_local.hpp", "spock_gpu_exec.hpp", "spock_device.hpp", "spock_group.hpp", "spock_igroup.hpp", "spock_ilevel.hpp", "spock_build.hpp", "spock_shapes.hpp", "spock_internal.hpp", "spock_rt.hpp", "spock_sp.hpp", "spock_team_local.hpp", os.path.join("..", "..", "include", "spock_amd.h")]
 _API = os.path.join("..", "..", "include", "spock_amd.h")
 DEPS = {   # headers each translation unit includes
-    "spock_kernels.hip": ["spock_device.hpp", "spock_group.hpp", "spock_team_local.hpp", "spock_sp.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
+    "spock_fkernels.hip": ["spock_flat_local.hpp", "spock_gpu_exec.hpp", "spock_device.hpp", "spock_team_local.hpp", "spock_internal.hpp"],
+    "spock_kernels.hip": ["spock_gpu_exec.hpp", "spock_device.hpp", "spock_group.hpp", "spock_team_local.hpp", "spock_sp.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
     "spock_ikernels.hip": ["spock_device.hpp", "spock_igroup.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
     "spock_lkernels.hip": ["spock_device.hpp", "spock_igroup.hpp", "spock_ilevel.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
     "spock_bkernels.hip": ["spock_device.hpp", "spock_build.hpp", "spock_internal.hpp"],
@@ -65,7 +66,7 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, tm
         return o
 
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:   # the two kernel files take minutes each: side by side
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:   # the two kernel files take minutes each: side by side
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:

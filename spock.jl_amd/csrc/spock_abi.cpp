@@ -45,6 +45,11 @@ struct spock_handle_s {
     int sp_variant = 0, sp_max_bt = 8;   // SP: 0 = the reference's run_sp! as it stands, 1 = corrected Anderson + working line search
     bool sp_fused = false;   // SP: the inner products with the residuals come out of phase B instead of out of LOP kernels
     bool fused = false;   // CP iteration = CROWN + SUB_BA (after one SUB_A) instead of SUB_A + CROWN + SUB_B
+    // lane-team shapes (large nx / nu): the node-local phases as flat kernels over chunks of nodes (spock_flat_local.hpp); the subtree /
+    // crown kernels then run the sweeps only.  CP: FLAT_A once, then SUB_A + CROWN + SUB_B + FLAT_BA per iteration (fused) or
+    // FLAT_A + SUB_A + CROWN + SUB_B + FLAT_B
+    bool flat_local = false;
+    int flat_chunks = 0;
     real *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_x0 = nullptr, *d_xlbuf = nullptr;
     double *d_partials = nullptr, *d_hist = nullptr;   // residual maxima / sums and the residual log stay double
     // element-major batched regime (spock_igroup.hpp): the iterate as [element][bp]; d_z / d_v then serve as instance-major
@@ -66,6 +71,11 @@ struct spock_handle_s {
     real *s_vec[10] = {nullptr}, *s_MP = nullptr, *s_Q = nullptr;
     double *s_partF = nullptr, *s_partL = nullptr;
     SpCtl *s_ctl = nullptr;
+    // closed loop chained on the device (SP_CTL_M): buffers kept in the handle between calls, a graph of their own
+    void *graph_mpc = nullptr;
+    int *m_w = nullptr, *m_t = nullptr, m_cap_steps = 0, m_graph_steps = 0;
+    real *m_xt = nullptr, *m_ut = nullptr;
+    double *m_res = nullptr;
     std::vector<SpCtl> h_sp;
     std::vector<Ctl> h_ctl;
     double last_ms = 0.;
@@ -146,6 +156,7 @@ KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
         a.ilv = 1; a.bp = h->bpad; a.cq = h->i_cq; a.want_xi = h->want_xi;
     }
     a.xlbuf = h->d_xlbuf;
+    a.flat_local = (!op && h->flat_local) ? 1 : 0; a.flat_chunks = h->flat_chunks;
     a.parity = parity;
     a.flags = flags;
     return a;
@@ -188,6 +199,14 @@ int launch_cp_iteration(spock_handle_s *h, int k, unsigned flags = 0, void *stre
         return e;
     }
     int e = 0;
+    if (h->flat_local) {   // sweeps in the subtree / crown kernels, node-local phases in the flat kernels
+        if (!h->fused) e = launch_group(MODE_FLAT_A, a, stream);
+        if (e == 0) e = launch_group(MODE_SUB_A, a, stream);
+        if (e == 0) e = launch_group(MODE_CROWN, a, stream);
+        if (e == 0) e = launch_group(MODE_SUB_B, a, stream);
+        if (e == 0) e = launch_group(h->fused ? MODE_FLAT_BA : MODE_FLAT_B, a, stream);
+        return e;
+    }
     if (!h->fused) e = launch_group(MODE_SUB_A, a, stream);
     if (e == 0) e = launch_group(MODE_CROWN, a, stream);
     if (e == 0) e = launch_group(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), a, stream);
@@ -220,7 +239,7 @@ int cp_prologue(spock_handle_s *h, unsigned flags = 0) {
     if (h->ilv && h->bp.dm.ilv_stream) {
         KArgs a = make_args(h, false, 0, flags);
         for (int t = h->bp.dm.N - 2; t >= h->bp.dm.t0 && e == 0; --t) { a.grp_level = t; e = launch_group(MODE_LA0, a, h->stream); }
-    } else e = launch_group(MODE_SUB_A, make_args(h, false, 0, flags), h->stream);
+    } else e = launch_group(h->flat_local ? MODE_FLAT_A : MODE_SUB_A, make_args(h, false, 0, flags), h->stream);
     if (e == 0 && h->ilv) e = launch_group(MODE_ICROWN_A, make_args(h, false, 0, flags), h->stream);
     return e;
 }
@@ -261,6 +280,10 @@ int time_cp_sequences(spock_handle_s *h);
 int choose_cp_sequence(spock_handle_s *h) {
     const Dims &dm = h->bp.dm;
     if (h->ilv) { h->fused = true; return 0; }   // the element-major regime has the fused sequence only
+    if (h->flat_local) {   // flat node-local kernels: phase B of iteration k and phase A of k + 1 in one launch (FLAT_BA)
+        h->fused = !(std::getenv("SPOCK_AMD_FLAT_FUSE") && std::getenv("SPOCK_AMD_FLAT_FUSE")[0] == '0');
+        return 0;
+    }
     h->fused = dm.t0 > 0 && (dm.nx + dm.nu <= 8);
     if (std::getenv("SPOCK_AMD_NO_FUSE")) { h->fused = false; return 0; }
     if (const char *e = std::getenv("SPOCK_AMD_FUSE")) {
@@ -354,8 +377,9 @@ SpArgs make_sp_args(spock_handle_s *h, int op) {
     a.nr = (long)dm.nz + dm.nv;
     a.n_partF = sp_flat_blocks(a.nr); a.n_partL = sp_lop_blocks(dm);
     a.batch = h->batch; a.op = op;
-    a.partG = h->d_partials; a.n_partG = dm.t0 > 0 ? dm.nsub + 1 : 1; a.fused_lop = h->sp_fused ? 1 : 0;
+    a.partG = h->d_partials; a.n_partG = h->flat_local ? h->flat_chunks : (dm.t0 > 0 ? dm.nsub + 1 : 1); a.fused_lop = h->sp_fused ? 1 : 0;
     a.variant = h->sp_variant; a.tau = 1.; a.trial = 0; a.last_trial = 1;
+    a.mpc_w = h->m_w; a.mpc_x0 = h->d_x0; a.mpc_xt = h->m_xt; a.mpc_ut = h->m_ut; a.mpc_res = h->m_res; a.mpc_t = h->m_t; a.mpc_steps = h->m_graph_steps;
     return a;
 }
 
@@ -368,7 +392,16 @@ int launch_sp_T(spock_handle_s *h, real *in, real *out, int sp_mode = 0, const r
     a.stride_z = a.stride_v = (long)dm.nz + dm.nv;
     a.hist = nullptr; a.hist_cap = 0;
     if (dm.t0 == 0) return launch_group(a.sp_mode ? MODE_FULL_SP : MODE_FULL, a, h->stream);
-    int e = launch_group(MODE_SUB_A, a, h->stream);
+    int e = 0;
+    if (h->flat_local) {
+        e = launch_group(MODE_FLAT_A, a, h->stream);
+        if (!e) e = launch_group(MODE_SUB_A, a, h->stream);
+        if (!e) e = launch_group(MODE_CROWN, a, h->stream);
+        if (!e) e = launch_group(MODE_SUB_B, a, h->stream);
+        if (!e) e = launch_group(a.sp_mode ? MODE_FLAT_B_SP : MODE_FLAT_B, a, h->stream);
+        return e;
+    }
+    e = launch_group(MODE_SUB_A, a, h->stream);
     if (!e) e = launch_group(MODE_CROWN, a, h->stream);
     if (!e) e = launch_group(a.sp_mode ? MODE_SUB_B_SP : MODE_SUB_B, a, h->stream);
     return e;
@@ -488,6 +521,94 @@ int sp_solve(spock_handle_s *h, const double *x0, double tol, int verbose, const
             spock_result_t &r = results[b];
             r.status = c.status; r.iterations = c.evals; r.iter_ref = c.iter; r.reserved = 0;
             r.xi1 = c.xi1; r.xi2 = c.xi2; r.xi = c.xi; r.solve_ms = ms;
+        }
+    }
+    h->last_ms = ms; h->last_iters = evals;
+    return SPOCK_OK;
+}
+
+// Closed-loop simulations with the steps chained ON THE DEVICE (SP, the reference's algorithm as it stands): every instance runs its own
+// sequence solve -> apply u -> advance x0 -> next warm-started solve; the control kernel SP_CTL_M at the end of an iteration does for a
+// finished instance what mpc_simulation.jl:47-54,164-177 does between two solve_model! calls.  No host decision per step and no instance
+// waits for the slowest one of its batch: the host replays a graph of G iterations and polls the control blocks until every instance
+// has done its last step.  (The host loop -- one solve call per step, all instances in lockstep -- remains for CP and SPOCK_AMD_MPC_HOST=1.)
+int sp_mpc_chain(spock_handle_s *h, const double *x0, int steps, const int32_t *w_seq, double tol, int verbose,
+                 double *x_traj, double *u_traj, spock_result_t *results) {
+    const Dims &dm = h->bp.dm;
+    const size_t B = (size_t)h->batch;
+    double gamma = 0.99 / std::sqrt(h->L_norm), sigma = gamma;                     // cp.jl:198-201
+    if (steps > h->m_cap_steps) {   // (grown buffers stay with the handle; the old ones are released with it)
+        int e = dev_alloc(h, &h->m_w, B * steps);
+        if (!e) e = dev_alloc(h, &h->m_t, B);
+        if (!e) e = dev_alloc(h, &h->m_xt, B * (size_t)(steps + 1) * dm.nx);
+        if (!e) e = dev_alloc(h, &h->m_ut, B * (size_t)steps * dm.nu);
+        if (!e) e = dev_alloc(h, &h->m_res, B * (size_t)steps * kMpcRec);
+        if (e) return fail(SPOCK_ERR_HIP, std::string("hipMalloc(trajectories): ") + rt::err(e));
+        h->m_cap_steps = steps;
+        if (h->graph_mpc) { rt::graph_destroy(h->graph_mpc); h->graph_mpc = nullptr; }
+    }
+    if (h->graph_mpc && h->m_graph_steps != steps) { rt::graph_destroy(h->graph_mpc); h->graph_mpc = nullptr; }
+    h->m_graph_steps = steps;
+    RTCHECK(rt::h2d(h->m_w, w_seq, B * steps * sizeof(int), h->stream));
+    RTCHECK(rt::dzero(h->m_t, B * sizeof(int), h->stream));
+    RTCHECK(up(h, h->d_x0, x0, B * dm.nx));
+    h->h_ctl.assign(B, fresh_ctl(h, gamma, sigma, tol, verbose));
+    RTCHECK(rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream));
+    RTCHECK(rt::d2h(h->h_sp.data(), h->s_ctl, B * sizeof(SpCtl), h->stream));
+    RTCHECK(rt::sync(h->stream));
+    for (auto &c : h->h_sp) { c.k = 0; c.r_safe = INFINITY; c.rnorm = INFINITY; c.rtilde = INFINITY; c.accept = 0; c.backtrack = 0; }
+    RTCHECK(rt::h2d(h->s_ctl, h->h_sp.data(), B * sizeof(SpCtl), h->stream));
+
+    int G = 16;
+    if (const char *e = std::getenv("SPOCK_AMD_MPC_GRAPH_ITERS")) { G = std::atoi(e); if (G < 1) G = 1; }
+    auto launch_G = [&]() {
+        int e = 0;
+        for (int it = 0; it < G && e == 0; ++it) {
+            e = launch_sp_iteration(h);
+            if (!e) e = launch_sp(make_sp_args(h, SP_CTL_M), h->stream);
+        }
+        return e;
+    };
+    const bool use_graph = h->graph_iters > 0 && rt::graphs_supported();
+    if (use_graph && !h->graph_mpc) {
+        RTCHECK(rt::capture_begin(h->stream));
+        const int e = launch_G();
+        void *exec = nullptr;
+        const int e2 = rt::capture_end(h->stream, &exec);
+        if (e) return fail(SPOCK_ERR_HIP, std::string("kernel launch during capture: ") + rt::err(e));
+        if (e2) return fail(SPOCK_ERR_HIP, std::string("hipStreamEndCapture/hipGraphInstantiate: ") + rt::err(e2));
+        h->graph_mpc = exec;
+    }
+    RTCHECK(rt::event_record(h->ev0, h->stream));
+    const long max_reps = ((long)steps * (h->max_iter + 2) + G - 1) / G + 2;
+    bool all_done = false;
+    for (long rep = 0; rep < max_reps && !all_done; ++rep) {
+        if (use_graph) RTCHECK(rt::graph_launch(h->graph_mpc, h->stream));
+        else RTCHECK(launch_G());
+        RTCHECK(rt::d2h(h->h_ctl.data(), h->d_ctl, B * sizeof(Ctl), h->stream));
+        RTCHECK(rt::sync(h->stream));
+        all_done = true;
+        for (const Ctl &c : h->h_ctl) all_done = all_done && (c.done == 1);
+    }
+    RTCHECK(rt::event_record(h->ev1, h->stream));
+    RTCHECK(rt::sync(h->stream));
+    float ms = 0.f;
+    RTCHECK(rt::event_elapsed(&ms, h->ev0, h->ev1));
+    if (!all_done) return fail(SPOCK_ERR_HIP, "closed loop did not terminate (internal error)");
+    std::vector<double> rec(B * (size_t)steps * kMpcRec);
+    RTCHECK(rt::d2h(rec.data(), h->m_res, rec.size() * sizeof(double), h->stream));
+    if (x_traj) RTCHECK(down(h, x_traj, h->m_xt, B * (size_t)(steps + 1) * dm.nx));
+    if (u_traj) RTCHECK(down(h, u_traj, h->m_ut, B * (size_t)steps * dm.nu));
+    RTCHECK(rt::sync(h->stream));
+    int evals = 0;
+    for (size_t k = 0; k < B * (size_t)steps; ++k) {
+        const double *r = rec.data() + k * kMpcRec;
+        evals += (int)r[1];
+        if (results) {
+            spock_result_t &o = results[k];
+            o.status = (int)r[0]; o.iterations = (int)r[1]; o.iter_ref = (int)r[2]; o.reserved = 0;
+            o.xi1 = r[3]; o.xi2 = r[4]; o.xi = r[5];
+            o.solve_ms = ms / steps;   // the steps of different instances overlap: the whole call's device time, per step
         }
     }
     h->last_ms = ms; h->last_iters = evals;
@@ -662,9 +783,12 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
             (e = dev_alloc(h, &h->s_partL, B * (size_t)sp_lop_blocks(dm) * kSpSums)) || (e = dev_alloc(h, &h->s_ctl, B)))
             return bail(e, "hipMalloc(SP state)");
     }
+    h->flat_local = !h->ilv && flat_local_applies(dm, h->batch);
+    h->flat_chunks = h->flat_local ? flat_geometry(dm).chunks : 0;
     h->hist_cap = h->max_iter + 2;
+    const size_t n_groups_part = (size_t)((h->flat_chunks > dm.nsub + 1) ? h->flat_chunks : dm.nsub + 1);
     const size_t n_part = h->ilv ? (size_t)(h->bpad / 64) * (size_t)(dm.n_bslots + dm.n_crown_groups) * 3 * 64
-                                 : B * (dm.nsub + 1) * kPartialStride;
+                                 : B * n_groups_part * kPartialStride;
     if ((e = dev_alloc(h, &h->d_dbuf, W * dm.nn * dm.nu)) || (e = dev_alloc(h, &h->d_qroot, W * dm.nsub * dm.nx)) ||
         (e = dev_alloc(h, &h->d_cbuf, W * (size_t)(group_threads(dm.d, dm.t0 + 1) + 1) * (dm.nx + dm.nu))) ||
         (e = dev_alloc(h, &h->d_partials, n_part)) || (e = dev_alloc(h, &h->d_x0, B * dm.nx)) ||
@@ -695,6 +819,7 @@ int spock_destroy(spock_handle_t h) {
     if (h->stream) rt::sync(h->stream);
     if (h->graph) rt::graph_destroy(h->graph);
     if (h->graph_log) rt::graph_destroy(h->graph_log);
+    if (h->graph_mpc) rt::graph_destroy(h->graph_mpc);
     for (void *st : h->tg_stream) if (st) { rt::sync(st); rt::stream_destroy(st); }
     for (void *ev : h->tg_event) if (ev) rt::event_destroy(ev);
     if (h->ev_fork) rt::event_destroy(h->ev_fork);
@@ -741,6 +866,13 @@ int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const 
     const size_t B = (size_t)h->batch;
     for (size_t k = 0; k < B * (size_t)steps; ++k)
         if (w_seq[k] < 0 || w_seq[k] >= dm.d) return fail(SPOCK_ERR_BAD_ARG, "w_seq entries must be events in [0, d)");
+    if (verbose != SPOCK_SILENT && verbose != SPOCK_LOG) return fail(SPOCK_ERR_BAD_ARG, "verbose must be SPOCK_SILENT or SPOCK_LOG");
+    if (!(tol >= 0.)) return fail(SPOCK_ERR_BAD_ARG, "tol must be non-negative");
+    {
+        const char *e = std::getenv("SPOCK_AMD_MPC_HOST");
+        if (h->alg == SPOCK_ALG_SP && h->sp_variant == 0 && h->sp_fused && !(e && e[0] == '1'))
+            return sp_mpc_chain(h, x0, steps, w_seq, tol, verbose, x_traj, u_traj, results);
+    }
     int *d_w = nullptr;
     real *d_xt = nullptr, *d_ut = nullptr;
     void *pw = nullptr, *pxt = nullptr, *put = nullptr;
@@ -1106,12 +1238,17 @@ static int profile_impl(spock_handle_t h, int32_t reps, double *avg_ms, int32_t 
     const bool stream_lv = h->ilv && pdm.ilv_stream;
     if (split && h->fused) {
         if (stream_lv) for (int t = pdm.N - 2; t >= pdm.t0; --t) push(MODE_LA0, 0, t);
-        else push(MODE_SUB_A, 0);
+        else push(h->flat_local ? MODE_FLAT_A : MODE_SUB_A, 0);
         if (h->ilv) push(MODE_ICROWN_A, 0);
     }
     const size_t n_prologue = seq.size();
     for (int it = 0; it < reps; ++it) {
         if (!split) { push(MODE_FULL, it); continue; }
+        if (h->flat_local) {
+            if (!h->fused) push(MODE_FLAT_A, it);
+            push(MODE_SUB_A, it); push(MODE_CROWN, it); push(MODE_SUB_B, it); push(h->fused ? MODE_FLAT_BA : MODE_FLAT_B, it);
+            continue;
+        }
         if (!h->fused) push(MODE_SUB_A, it);
         if (h->ilv) for (int lv = pdm.n_lv - 2; lv >= 1; --lv) push(MODE_I_UP, it, lv);
         push(MODE_CROWN, it);
@@ -1143,7 +1280,7 @@ static int profile_impl(spock_handle_t h, int32_t reps, double *avg_ms, int32_t 
         if (k >= n_prologue && per_it) it_sum[(k - n_prologue) % per_it] += ms;
         // (element-major regime: the crown's node-local kernels count with the crown, kind 1)
         // (level-streaming kernels: the bottom stage's LBA is kind 2, the other stages' LB / LA count with the crown)
-        const int kind = (seq[k] == MODE_SUB_A || seq[k] == MODE_ICROWN_A || seq[k] == MODE_LA0) ? 0
+        const int kind = (seq[k] == MODE_SUB_A || seq[k] == MODE_ICROWN_A || seq[k] == MODE_LA0 || seq[k] == MODE_FLAT_A) ? 0
                          : (seq[k] == MODE_CROWN || seq[k] == MODE_I_UP || seq[k] == MODE_I_DOWN || seq[k] == MODE_LB || seq[k] == MODE_LA) ? 1 : seq[k] == MODE_FULL ? 3 : 2;
         sum[kind] += ms; cnt[kind] += 1;
     }

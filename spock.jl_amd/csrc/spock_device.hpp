@@ -82,6 +82,22 @@ struct DynDims {
     SPK_DEV int ny() const { return ny_; }
 };
 
+// Lane-team policy with the branching factor at COMPILE time, for the flat node-local kernels (spock_flat_local.hpp): the loops over
+// the children unroll and the per-child values a lane carries from part 1 to part 2 of a phase (TLReg) stay in registers.  With a
+// run-time d they are dynamically indexed arrays, i.e. scratch memory -- 672 B per lane in the first build of those kernels, and
+// the reason the lane-team phases of the subtree kernels were slow.  nx, nu, ny stay run-time values (no per-lane vectors exist).
+template <int D>
+struct FlatDims {
+    static constexpr int MAXNX = 1, MAXNU = 1, MAXD = D, MAXNY = 1, MAXM = 1, UNR = 8;
+    static constexpr bool DIAG = true, SHARED = true, REGROWS = false, TEAMLOCAL = true, MFMA_SWEEP = false;
+    int nx_, nu_, ny_;
+    SPK_DEV explicit FlatDims(const Dims &dm) : nx_(dm.nx), nu_(dm.nu), ny_(dm.ny) {}
+    SPK_DEV int nx() const { return nx_; }
+    SPK_DEV int nu() const { return nu_; }
+    SPK_DEV constexpr int d() const { return D; }
+    SPK_DEV int ny() const { return ny_; }
+};
+
 // lane-team node-local phases (spock_team_local.hpp): per-lane registers carried from part 1 to part 2 of a phase
 template <class P>
 struct TLReg {

@@ -29,10 +29,12 @@
 
 namespace spock {
 
+#ifndef SPK_LAMBDA_INLINE
 #ifdef SPOCK_HOST_EMU
 #define SPK_LAMBDA_INLINE
 #else
 #define SPK_LAMBDA_INLINE __attribute__((always_inline))
+#endif
 #endif
 
 SPK_DEV int group_threads_dev(int d, int stages) {   // non-leaf nodes of a complete d-ary tree with `stages` stages
@@ -49,7 +51,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     const P p(dm);
     const unsigned flags = a.flags;
     Ctl &ctl = a.ctl[inst];
-    const int n_groups = dm.t0 > 0 ? dm.nsub + 1 : 1;
+    // flat node-local kernels (spock_flat_local.hpp; lane-team shapes): this kernel then runs the S1 sweeps only -- c_i, e_i and the
+    // leaves' q come from zbar's x / u entries, where MODE_FLAT_A parked them -- and the flat kernels' workgroups own the partials
+    const bool flat = P::TEAMLOCAL && a.flat_local != 0;
+    const int n_groups = flat ? a.flat_chunks : (dm.t0 > 0 ? dm.nsub + 1 : 1);
     double *partials = a.partials + (long)inst * n_groups * kPartialStride;
 
     int stamp_idx = 0;
@@ -176,7 +181,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 const int k = tid + j * x.nthreads();
                 real val = 0.;
                 if (MODE == MODE_CROWN) {
-                    if (k < st_n1) val = cb[k];
+                    if (k < st_n1) val = flat ? (k < nl_grp * p.nx() ? zo[dm.zx + k] : zo[dm.zu + (k - nl_grp * p.nx())]) : cb[k];   // (crown nodes = global nodes 0 ..)
                     else if (k < st_n1 + st_n2) val = qg[k - st_n1];
                 } else if (k < st_n1) {   // element k of ED: local node k / nu sits in the level chunk that contains it
                     const int li = k / p.nu(), comp = k - li * p.nu();
@@ -206,6 +211,20 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // ---- phase A (node-local) on the iterate (zi, vi); its part of zbar goes to zout, c_i / e_i (and the leaves' xbar) to
     //      the thread state or the lane teams' LDS vectors, for the crown's extra workgroup to cbuf
     auto phase_a = [&](const real *zi, const real *vi, real *zout, const real *v2x) SPK_LAMBDA_INLINE {
+        if (flat) {   // c_i, e_i, q_leaf of this subtree: zbar's x / u entries -> the lane teams' LDS vectors (level chunks are contiguous)
+            if (crown_blk || !sweeping) return;
+            x.each([&](int tid, TState<P> &) {
+                for (int l = 0; l <= stages - 2; ++l) {
+                    int lfirst, cnt; long gfirst;
+                    level_geo(l, lfirst, cnt, gfirst);
+                    for (int k = tid; k < cnt * nx; k += nthr) tl.XQ[lfirst * nx + k] = zout[dm.zx + gfirst * nx + k];
+                    for (int k = tid; k < cnt * nu; k += nthr) tl.ED[lfirst * nu + k] = zout[dm.zu + gfirst * nu + k];
+                }
+                const long gl_first = dm.first[root_stage + stages - 1] + (long)root_pos * ngl_grp;
+                for (int k = tid; k < ngl_grp * nx; k += nthr) tl.XL[k] = zout[dm.zx + gl_first * nx + k];
+            });
+            return;   // (backward() starts with a barrier)
+        }
         if (flags & F_NO_ALOCAL) return;
         if (team_local) {
             for (int base = 0; base < nl_grp; base += nteams) {
@@ -263,8 +282,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                             else if (k < st_n1 + st_n2) tl.XL[k - st_n1] = s.stg[j];
                         }
                     } else {
-                        for (int k = tid; k < nl_grp * nx; k += nthr) tl.XQ[k] = cb[k];
-                        for (int k = tid; k < nl_grp * nu; k += nthr) tl.ED[k] = cb[nl_grp * nx + k];
+                        for (int k = tid; k < nl_grp * nx; k += nthr) tl.XQ[k] = flat ? zo[dm.zx + k] : cb[k];
+                        for (int k = tid; k < nl_grp * nu; k += nthr) tl.ED[k] = flat ? zo[dm.zu + k] : cb[nl_grp * nx + k];
                         for (int k = tid; k < ngl_grp * nx; k += nthr) tl.XL[k] = qg[k];
                     }
                 });
@@ -460,7 +479,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         return ps;
     };
     auto phase_b = [&]() SPK_LAMBDA_INLINE {
-        if (flags & F_NO_BLOCAL) return;
+        if ((flags & F_NO_BLOCAL) || flat) return;
         const ProxScal ps = make_ps();
         const unsigned bflags = crown_blk ? (flags | F_NO_SWEEP) : flags;   // the crown's x, u come from zbar
         if (team_local) {
@@ -573,6 +592,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     };
 
     // ---- the kernel's sequence
+    if (flat && crown_blk) return;   // the crown's node-local phases run in the flat kernels
     if (MODE == MODE_FULL || MODE == MODE_SUB_A) {
         phase_a(z, v, zo, nullptr);
         if (crown_blk) return;

@@ -219,6 +219,31 @@ bool team_local_applies(const Dims &dm) {
     return big && dm.diag_costs && dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1 && !dm.risk_has_soc;
 }
 
+// Flat node-local kernels (spock_flat_local.hpp): T lanes per node as in the subtree kernels' lane teams; a team is part of ONE wave
+// and the waves of a workgroup share nothing but the final reduction, so workgroups are small -- 256 threads: 4 nodes at T = 64
+// (nx = 64 / 50), 8 at T = 32 (nx = 20) -- and a launch has thousands of them.
+FlatGeo flat_geometry(const Dims &dm) {
+    FlatGeo g;
+    int T = 8;
+    while (T < dm.nx || T < dm.nu) T *= 2;
+    g.team = T;
+    int thr = 256;
+    if (const char *e = std::getenv("SPOCK_AMD_FLAT_THREADS")) { thr = std::atoi(e); if (thr < 64) thr = 64; if (thr > 256) thr = 256; thr = (thr / 64) * 64; }
+    g.threads = thr;
+    g.nteams = g.threads / T;
+    g.chunks = (dm.nn + g.nteams - 1) / g.nteams;
+    const int m = dm.ny + 2 * dm.d;
+    // per team: flat_scratch_doubles, sized for the host emulation's extra rows too (the GPU uses the first m + nu + d doubles)
+    g.ex_doubles = g.nteams * (m + dm.nu + dm.d + (2 + 3 * dm.d) * T);
+    g.lds_bytes = (size_t)g.ex_doubles * 8 + (4 + 128 + 64) * 8;          // + the reduction scratch / stamps / SP sums of the group kernels' carve
+    return g;
+}
+bool flat_local_applies(const Dims &dm, int batch) {
+    if (const char *e = std::getenv("SPOCK_AMD_FLAT_LOCAL")) { if (e[0] == '0') return false; }
+    if (dm.t0 <= 0) return false;                                  // whole tree in one workgroup: nothing to flatten
+    return launch_geometry(MODE_SUB_A, dm, batch).team_local != 0 && launch_geometry(MODE_CROWN, dm, batch).team_local != 0;
+}
+
 LaunchGeo launch_geometry(int mode, const Dims &dm, int batch) {
     LaunchGeo g;
     if (mode == MODE_SUB_B_SP || mode == MODE_SUB_B_LAT) mode = MODE_SUB_B;

@@ -135,6 +135,10 @@ struct KArgs {
     int grp_level;              // element-major regime, I_UP / I_DOWN: the layer of mid groups this launch works on
     int tile0, n_tiles;         // element-major regime: the launch covers tiles tile0 .. tile0 + n_tiles - 1 (n_tiles 0 = all)
     int ls_cnt, ls_first, ls_first_child, ls_slot, ls_chunk_k;   // level kernels (grp_level = the stage): filled by the launcher from IlvGeo
+    // flat node-local kernels (spock_flat_local.hpp): 1 = SUB_A / CROWN / SUB_B run the sweeps only (c_i, e_i, q_leaf come from
+    // zbar's x / u entries, x_i, u_i go back there), the node-local phases run as MODE_FLAT_A / MODE_FLAT_B over `flat_chunks`
+    // workgroups per instance, which also own the residual partial slots
+    int flat_local, flat_chunks;
 };
 
 // ---- SP (SuperMann + Anderson) driver: plain data shared by the kernels (spock_sp.hpp) and the driver ----
@@ -176,12 +180,22 @@ struct SpArgs {
     int variant;
     int trial, last_trial;     // line search: index of the candidate this launch belongs to, 1 if no further candidate follows
     double tau;                // its step: beta^trial
+    // closed loop chained on the device (SP_CTL_M; examples/server_heat/mpc_simulation.jl:47-54,164-177): per instance the step it is at,
+    // its disturbance sequence, x0 (advanced in place), the trajectories and one record per step [status, evals, iter, xi1, xi2, xi]
+    const int *mpc_w;
+    real *mpc_x0, *mpc_xt, *mpc_ut;
+    double *mpc_res;
+    int *mpc_t;
+    int mpc_steps;
 };
+constexpr int kMpcRec = 6;
 
 enum SpOp { SP_FLAT1 = 1, SP_FLAT2, SP_FLAT3, SP_FLAT4, SP_FLAT5, SP_LOP_R, SP_LOP_RT, SP_LOP_DP,
             SP_CTL_A, SP_CTL_B, SP_CTL_C, SP_CTL_D, SP_CTL_CD,
             SP_FLATW = 20,    // corrected variant: the next line-search candidate W = Z + tau D
-            SP_CTL_E = 21 };  // corrected variant: end of an iteration, instances parked by an accepted candidate (done == 3) run on
+            SP_CTL_E = 21,    // corrected variant: end of an iteration, instances parked by an accepted candidate (done == 3) run on
+            SP_CTL_M = 22 };  // closed loop on the device, end of an iteration: an instance whose solve has just ended (done == 2, final update
+                              // applied) records the step, applies u, advances x0 and re-arms itself for the next warm-started solve
 
 // MODE_SUB_B_SP / MODE_FULL_SP: SUB_B / FULL whose phase B also accumulates the SP driver's inner products (KArgs::sp_mode);
 // separate kernels so that the CP kernels do not carry that code and its registers
@@ -196,7 +210,13 @@ enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, 
                  MODE_LBA = 13,   // bottom stage (children = leaves): forward step, phase B, next phase A, backward step
                  MODE_LA = 14,    // next phase A + backward step of one non-bottom stage (bottom-up), on (zbar, vbar) -> znext
                  MODE_LA0 = 15,   // prologue: phase A + backward step of iteration 0 on (z, v) -> zbar, any streamed stage
-                 N_ALL_MODES = 16 };
+                 // flat node-local kernels of the lane-team shapes (large nx / nu; spock_flat_local.hpp): the node-local phases leave the
+                 // one-workgroup-per-subtree kernels and run over chunks of consecutive non-leaf nodes, ~1000 workgroups per instance
+                 MODE_FLAT_A = 16,     // phase A of every non-leaf node: c_i, e_i and the leaves' q = -xbar parked in zbar's x / u entries
+                 MODE_FLAT_B = 17,     // phase B of every non-leaf node on the zbar the sweeps completed; residual maxima per workgroup
+                 MODE_FLAT_B_SP = 18,  // ... plus the SP driver's inner products (KArgs::sp_mode)
+                 MODE_FLAT_BA = 19,    // phase B of iteration k and phase A of iteration k + 1 on the iterate just produced, one launch
+                 N_ALL_MODES = 20 };
 
 // ---- host build step (spock_host.cpp) -------------------------------------------------------------
 struct HostProblem {
@@ -222,6 +242,10 @@ int choose_split_stage(int N, int d, int nx, int nu = 0, int batch = 1);
 struct LaunchGeo { int threads, grid_x, team, team_reg, team_local, lds_mats, ex_doubles, xl_global, xl_stride; size_t lds_bytes; };
 bool team_local_applies(const Dims &dm);   // lane-team node-local phases: large nx / nu, shared diagonal costs, no SOC risk cone
 LaunchGeo launch_geometry(int mode, const Dims &dm, int batch);
+// flat node-local kernels: lanes per node, threads per workgroup (= one round of threads / team nodes), workgroups per instance
+struct FlatGeo { int team, threads, nteams, chunks, ex_doubles; size_t lds_bytes; };
+FlatGeo flat_geometry(const Dims &dm);
+bool flat_local_applies(const Dims &dm, int batch);   // the handle runs its node-local phases as flat kernels
 int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tree with `stages` stages
 
 // element-major batched regime: split stage (subtrees of at most `max_sub_stages` stages, LDS-bound), launch geometry

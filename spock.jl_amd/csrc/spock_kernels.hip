@@ -8,73 +8,12 @@
 #include <cstdlib>
 
 #include "spock_group.hpp"
+#include "spock_gpu_exec.hpp"
 #include "spock_shapes.hpp"
 #include "spock_sp.hpp"
 #include "spock_team_local.hpp"
 
 namespace spock {
-
-template <class P>
-struct GpuExec {
-    TState<P> st;
-    double m[3];          // residual maxima: reduced in double whatever `real` is
-    real *ex, *lm;
-    unsigned long long *red, *stamps;
-    int *fl;
-    template <class F>
-    __device__ __forceinline__ void each(F &&f) { f((int)threadIdx.x, st); }
-    __device__ __forceinline__ void barrier() { __syncthreads(); }
-    __device__ __forceinline__ real *lds() { return ex; }
-    __device__ __forceinline__ real *lds_mats() { return lm; }
-    __device__ __forceinline__ int &flag() { return *fl; }
-    template <class T>
-    __device__ __forceinline__ void stash3(int, const T *mx) { m[0] = (double)mx[0]; m[1] = (double)mx[1]; m[2] = (double)mx[2]; }
-    __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
-    __device__ __forceinline__ unsigned long long *stamp_lds() { return stamps; }
-    __device__ __forceinline__ void clocks(unsigned long long *d) { d[0] = __builtin_readcyclecounter(); d[1] = __builtin_amdgcn_s_memrealtime(); }
-    // values are |.| (sign bit clear) or NaN: the unsigned order of the bit patterns is the
-    // NaN-propagating max order, so an integer max does the reduction
-    __device__ __forceinline__ void reduce3() {
-        __syncthreads();
-        if (threadIdx.x < 3) red[threadIdx.x] = 0ull;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            unsigned long long b = (unsigned long long)__double_as_longlong(m[k]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(b, off, 64);
-                b = o > b ? o : b;
-            }
-            if ((threadIdx.x & 63) == 0) atomicMax(&red[k], b);
-        }
-        __syncthreads();
-    }
-    __device__ __forceinline__ real red3(int k) const { return __longlong_as_double((long long)red[k]); }
-    // deterministic sums over the workgroup (SP inner products): fixed shuffle tree per wave, then the waves in order
-    double sm[3];
-    double *sums;   // LDS [3][16 waves] + [3] results
-    template <class T>
-    __device__ __forceinline__ void stash_sum3(int, const T *v) { sm[0] = (double)v[0]; sm[1] = (double)v[1]; sm[2] = (double)v[2]; }
-    __device__ __forceinline__ void reduce_sum3() {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            double v = sm[k];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) sums[k * 16 + wave] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            double v = sums[threadIdx.x * 16];
-            for (int w = 1; w < nw; ++w) v += sums[threadIdx.x * 16 + w];
-            sums[48 + threadIdx.x] = v;
-        }
-        __syncthreads();
-    }
-    __device__ __forceinline__ double sum3(int k) const { return sums[48 + k]; }
-};
 
 #ifdef SPOCK_WAVES_PER_EU   // experiment builds only
 #define SPK_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(SPOCK_WAVES_PER_EU)))
@@ -158,6 +97,8 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
 
 
 
+int launch_flat_local(int mode, const KArgs &a, void *stream);   // flat node-local kernels (spock_fkernels.hip)
+
 bool have_static_variant(int nx, int nu, int d, int ny) {
 #define X(a, b, c, e) if (nx == a && nu == b && d == c && ny == e) return true;
     SPOCK_STATIC_SHAPES(X)
@@ -171,6 +112,7 @@ int launch_group(int mode, const KArgs &a, void *stream) {
     const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
     static const bool force_dyn = std::getenv("SPOCK_AMD_FORCE_DYN") != nullptr;   // experiments: run-time-dimension kernels for every shape
     if (a.ilv) return launch_igroup(mode, a, stream);   // element-major batched regime (spock_ikernels.hip)
+    if (mode >= MODE_FLAT_A && mode <= MODE_FLAT_BA) return launch_flat_local(mode, a, stream);   // spock_fkernels.hip
 #define X(a_, b_, c_, e_)                                                                      \
     if (!force_dyn && dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                  \
         return cm == 2 ? launch_variant<StaticDims<a_, b_, c_, e_, 2>>(mode, a, st) : cm == 1 ? launch_variant<StaticDims<a_, b_, c_, e_, 1>>(mode, a, st)    \
@@ -281,6 +223,24 @@ __global__ void __launch_bounds__(512) spock_sp_lop_kernel(const SpArgs a) {
 __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs a) {
     const int inst = blockIdx.y;
     Ctl &ctl = a.ctl[inst];
+    if (a.op == SP_CTL_M) {   // closed loop on the device: the instance's solve has ended and FLAT5 has applied its last step
+        if (ctl.done != 2) return;
+        const Dims &dm = a.dm;
+        const int t = a.mpc_t[inst], r = threadIdx.x;
+        const real *z = a.Z + (long)inst * a.nr;
+        real *x0 = a.mpc_x0 + (long)inst * dm.nx;
+        const int w = a.mpc_w[(long)inst * a.mpc_steps + t];
+        real xn = 0.;
+        if (r < dm.nx) {
+            if (t == 0) a.mpc_xt[((long)inst * (a.mpc_steps + 1)) * dm.nx + r] = x0[r];
+            xn = mpc_advance_row(dm, (MatPtr)a.mats, z, 1, x0, w, r);       // u = z[u_inds[1:nu]], x0 <- A_w x0 + B_w u
+        }
+        if (r < dm.nu) a.mpc_ut[((long)inst * a.mpc_steps + t) * dm.nu + r] = z[dm.zu + r];
+        __syncthreads();   // every row has read the old x0 (and every thread the old `done`)
+        if (r < dm.nx) { x0[r] = xn; a.mpc_xt[((long)inst * (a.mpc_steps + 1) + t + 1) * dm.nx + r] = xn; }
+        if (r == 0) sp_mpc_next(ctl, a.sp[inst], a.mpc_t + inst, a.mpc_steps, a.mpc_res + (long)inst * a.mpc_steps * kMpcRec);
+        return;
+    }
     if (ctl.done) {
         if (a.op == SP_CTL_A && ctl.done == 2 && threadIdx.x == 0) ctl.done = 1;   // the final state update has run
         if (a.op == SP_CTL_E && ctl.done == 3 && threadIdx.x == 0) ctl.done = 0;   // corrected variant: parked by an accepted candidate
@@ -387,7 +347,7 @@ int launch_sp(const SpArgs &a, void *stream) {
         case SP_FLAT1: case SP_FLAT2: case SP_FLAT3: case SP_FLAT4: case SP_FLAT5: case SP_FLATW:
             hipLaunchKernelGGL(spock_sp_flat_kernel, dim3(a.n_partF, a.batch), dim3(kFlatThreads), 0, st, a);
             return (int)hipGetLastError();
-        case SP_CTL_A: case SP_CTL_B: case SP_CTL_C: case SP_CTL_D: case SP_CTL_CD: case SP_CTL_E:
+        case SP_CTL_A: case SP_CTL_B: case SP_CTL_C: case SP_CTL_D: case SP_CTL_CD: case SP_CTL_E: case SP_CTL_M:
             hipLaunchKernelGGL(spock_sp_ctl_kernel, dim3(1, a.batch), dim3(kCtlThreads), 0, st, a);
             return (int)hipGetLastError();
         default: break;

@@ -349,4 +349,21 @@ SPK_DEV void sp_ctl_trial(SpCtl &c, Ctl &ctl, double s_rt, double s_rtd, double 
     if (!ctl.done && !last) ctl.done = 3;
 }
 
+// Closed loop on the device: what run_sp!'s caller does between two warm-started solves (mpc_simulation.jl:47-54,164-177), for ONE
+// instance whose solve has just ended.  Thread 0 of the control kernel, after the rows of x0 <- A_w x0 + B_w u have been formed:
+// the record of step t, then either the control blocks of a fresh solve (what solve_model! / run_sp! reset: sp.jl:383-389,
+// models/spock.jl:231-251 -- the Anderson memory, R and z_old / r_old persist, that IS the warm start) or done = 1 after the last step.
+SPK_DEV void sp_mpc_next(Ctl &ctl, SpCtl &c, int *t_ptr, int steps, double *rec) {
+    const int t = *t_ptr;
+    double *r = rec + (long)t * kMpcRec;
+    r[0] = (double)ctl.status; r[1] = (double)ctl.evals; r[2] = (double)ctl.iter; r[3] = ctl.xi1; r[4] = ctl.xi2; r[5] = ctl.xi;
+    *t_ptr = t + 1;
+    if (t + 1 >= steps) { ctl.done = 1; return; }
+    ctl.status = 0; ctl.evals = 0; ctl.iter = 0; ctl.pending = 0; ctl.result_parity = 0;
+    ctl.res0[0] = -INFINITY; ctl.res0[1] = -INFINITY;
+    ctl.xi1 = NAN; ctl.xi2 = NAN; ctl.xi = NAN;
+    c.k = 0; c.r_safe = INFINITY; c.rnorm = INFINITY; c.rtilde = INFINITY; c.accept = 0; c.backtrack = 0;
+    ctl.done = 0;
+}
+
 }  // namespace spock

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../spock.jl_amd/csrc/spock_group.hpp"
+#include "../../spock.jl_amd/csrc/spock_flat_local.hpp"
 #include "../../spock.jl_amd/csrc/spock_igroup.hpp"
 #include "../../spock.jl_amd/csrc/spock_ilevel.hpp"
 #include "../../spock.jl_amd/csrc/spock_build.hpp"
@@ -40,6 +41,7 @@ struct EmuExec {
         else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t]);
     }
     void barrier() {}
+    void team_sync() {}
     // role waves: every thread up to the barrier, then every thread behind it
     template <class F>
     void phased(F &&f) {
@@ -113,6 +115,32 @@ static int launch_variant(int mode, const KArgs &a_in) {
     return 0;
 }
 
+
+// flat node-local kernels (spock_flat_local.hpp)
+template <class P, int MODE>
+static void run_flat_blocks(const KArgs &a, int gx, int thr) {
+    const bool rev = env_on("SPOCK_EMU_REVERSE_BLOCKS");
+    for (int inst = 0; inst < a.batch; ++inst)
+        for (int gi = 0; gi < gx; ++gi) {
+            const int g = rev ? gx - 1 - gi : gi;
+            EmuExec<P> x(thr, a.ex_doubles, 8);
+            flat_body<P, MODE>(x, a, inst, g);
+        }
+}
+template <class P>
+static int launch_flat(int mode, const KArgs &a_in) {
+    KArgs a = a_in;
+    const FlatGeo g = flat_geometry(a.dm);
+    a.team = g.team; a.ex_doubles = g.ex_doubles; a.flat_chunks = g.chunks;
+    switch (mode) {
+        case MODE_FLAT_A: run_flat_blocks<P, MODE_FLAT_A>(a, g.chunks, g.threads); break;
+        case MODE_FLAT_B: run_flat_blocks<P, MODE_FLAT_B>(a, g.chunks, g.threads); break;
+        case MODE_FLAT_B_SP: run_flat_blocks<P, MODE_FLAT_B_SP>(a, g.chunks, g.threads); break;
+        case MODE_FLAT_BA: run_flat_blocks<P, MODE_FLAT_BA>(a, g.chunks, g.threads); break;
+        default: return 1;
+    }
+    return 0;
+}
 
 // ---- element-major batched regime, emulated: the "threads" of a workgroup run one after the other between barriers -------
 template <class P>
@@ -235,6 +263,10 @@ int launch_group(int mode, const KArgs &a, void *) {
 #undef X
         return 9;
     }
+    if (mode >= MODE_FLAT_A && mode <= MODE_FLAT_BA) {
+        if (cm != 2 || !team_local_applies(dm)) return 9;
+        return dm.d == 2 ? launch_flat<FlatDims<2>>(mode, a) : dm.d == 3 ? launch_flat<FlatDims<3>>(mode, a) : launch_flat<FlatDims<4>>(mode, a);
+    }
     if (!env_on("SPOCK_EMU_FORCE_DYN")) {
 #define X(a_, b_, c_, e_)                                                                  \
     if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                            \
@@ -311,6 +343,25 @@ int launch_sp(const SpArgs &a, void *) {
                 real *dst = a.partF + ((long)inst * a.n_partF + blk) * kSpSums;
                 if (a.op == SP_FLAT1 || a.op == SP_FLAT2) for (int k = 0; k < 9; ++k) dst[k] = sums[k];
             }
+        }
+        return 0;
+    }
+    if (a.op == SP_CTL_M) {   // closed loop on the device (spock_kernels.hip: spock_sp_ctl_kernel)
+        for (int inst = 0; inst < a.batch; ++inst) {
+            Ctl &ctl = a.ctl[inst];
+            if (ctl.done != 2) continue;
+            const int t = a.mpc_t[inst];
+            const real *z = a.Z + (long)inst * a.nr;
+            real *x0 = a.mpc_x0 + (long)inst * dm.nx;
+            const int w = a.mpc_w[(long)inst * a.mpc_steps + t];
+            std::vector<real> xn(dm.nx);
+            for (int r = 0; r < dm.nx; ++r) {
+                if (t == 0) a.mpc_xt[((long)inst * (a.mpc_steps + 1)) * dm.nx + r] = x0[r];
+                xn[r] = mpc_advance_row(dm, (MatPtr)a.mats, z, 1, x0, w, r);
+            }
+            for (int r = 0; r < dm.nu; ++r) a.mpc_ut[((long)inst * a.mpc_steps + t) * dm.nu + r] = z[dm.zu + r];
+            for (int r = 0; r < dm.nx; ++r) { x0[r] = xn[r]; a.mpc_xt[((long)inst * (a.mpc_steps + 1) + t + 1) * dm.nx + r] = xn[r]; }
+            sp_mpc_next(ctl, a.sp[inst], a.mpc_t + inst, a.mpc_steps, a.mpc_res + (long)inst * a.mpc_steps * kMpcRec);
         }
         return 0;
     }

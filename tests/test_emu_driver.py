@@ -273,6 +273,37 @@ def test_emulated_mpc_closed_loop(S, O, emu):
     m.close()
 
 
+def test_emulated_mpc_steps_chained_on_the_device(S, O, emu, monkeypatch):
+    """SP closed loops with the steps chained on the device (SP_CTL_M: a finished instance records its step, applies u, advances x0
+    and re-arms itself; no instance waits for its batch) against the host loop of solve calls (SPOCK_AMD_MPC_HOST=1: all instances
+    in lockstep, one spock_solve per step): the instances are independent and run the same arithmetic, so per-step iteration
+    counts, statuses and trajectories are IDENTICAL, whatever the number of iterations per graph replay."""
+    specs = S.get_server_heat_specs(5, 5, 2)
+    B, steps = 3, 7
+    w = np.random.default_rng(4).integers(0, 2, size=(B, steps))
+    x0 = np.array([[0.1] * 5, [0.12, -0.05, 0.1, 0.02, 0.2], [-0.1, 0.1, 0.05, 0.0, 0.3]])
+    out = {}
+    for mode, env in (("chain", {}), ("chain3", {"SPOCK_AMD_MPC_GRAPH_ITERS": "3"}), ("host", {"SPOCK_AMD_MPC_HOST": "1"})):
+        for k in ("SPOCK_AMD_MPC_GRAPH_ITERS", "SPOCK_AMD_MPC_HOST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, batch=B, split_stage=2)
+        xt, ut, res = S.mpc_simulation(m, x0, w, tol=1e-3)
+        out[mode] = (xt, ut, [[(r["iterations"], r["status"]) for r in rb] for rb in res], m.solver_state.z.copy())
+        # a second call on the same model continues from the state left behind (warm start), as the reference's loop would
+        xt2, ut2, res2 = S.mpc_simulation(m, xt[:, -1], w[:, :3], tol=1e-3)
+        out[mode + "_2"] = (xt2, ut2, [[(r["iterations"], r["status"]) for r in rb] for rb in res2])
+        m.close()
+    its = [n for rb in out["host"][2] for n, _ in rb]
+    assert len(set(its)) > 2                                                  # the instances do stop at different iterations
+    for mode in ("chain", "chain3"):
+        assert out[mode][2] == out["host"][2] and out[mode + "_2"][2] == out["host_2"][2]
+        for k in (0, 1, 3):
+            assert np.array_equal(out[mode][k], out["host"][k])
+        assert np.array_equal(out[mode + "_2"][0], out["host_2"][0]) and np.array_equal(out[mode + "_2"][1], out["host_2"][1])
+
+
 def test_emulated_closed_form_L_norm(S, O, emu):
     """||L||^2 in closed form (3.2746 for the d = 2 AV@R server_heat data, the value the reference
     rounds up to its hard-coded 3.28) against power iteration on the oracle's L, and as the step-size source."""
@@ -421,6 +452,50 @@ def test_emulated_group_leaf_vector_in_global_memory(S, O, emu, monkeypatch):
     h = m.history(); n = min(20, len(h["xi1"]), len(ro["hist_xi1"]))
     assert np.max(np.abs(h["xi1"][:n] - ro["hist_xi1"][:n]) / ro["hist_xi1"][:n]) <= 1e-8 and r["status"] == 0
     m.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"SPOCK_AMD_FLAT_FUSE": "0"}, {"SPOCK_EMU_REVERSE": "1", "SPOCK_EMU_REVERSE_BLOCKS": "1"}])
+def test_emulated_flat_node_local_kernels(S, O, emu, monkeypatch, env):
+    """Lane-team shapes (nx > 8): the node-local phases as FLAT kernels over chunks of 16 nodes (spock_flat_local.hpp), the subtree /
+    crown kernels running the sweeps only -- c_i, e_i, q_leaf travel through zbar's own x / u entries.  CP runs FLAT_BA (phase B of
+    iteration k + phase A of k + 1, vbar.v2 of non-leaf children recomputed by the parent's team); SPOCK_AMD_FLAT_FUSE=0 the
+    separate FLAT_A / FLAT_B; SP always the separate ones with the inner products in FLAT_B_SP.  Against the oracle, in both
+    thread and workgroup orders; equal to rounding to the subtree kernels' own node-local phases (SPOCK_AMD_FLAT_LOCAL=0), whose
+    team-wide sums run in another order."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for specs, kw in ((S.get_random_linear_specs(5, 12, 4), {"split_stage": 2}), (S.get_server_heat_specs(6, 20, 2), {"split_stage": 3}),
+                      (S.get_server_heat_specs(5, 20, 3, p_ref=[0.2, 0.3, 0.5]), {"split_stage": 2, "L_norm": "auto"})):
+        flat = S.flatten_problem(*specs)
+        x0 = 0.1 * np.cos(np.arange(flat.nx))
+        m = S.build_model(*specs, lib_path=emu, max_iter=40, **kw)
+        seq = [n for n, _, _ in m.profile_sequence(1)]
+        assert seq == (["flat_a", "sub_a", "crown", "sub_b", "flat_b"] if env.get("SPOCK_AMD_FLAT_FUSE") == "0" else ["sub_a", "crown", "sub_b", "flat_ba"])
+        m.reset()
+        r = S.solve_model(m, x0, tol=1e-12, verbose=S.LOG)
+        o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm
+        ro = o.solve(x0, tol=1e-12, verbose=O.LOG, max_iter=40, history=50)
+        h = m.history()
+        assert r["iterations"] == ro["iterations"] == 40
+        assert np.max(np.abs(h["xi"] - ro["hist_xi"]) / ro["hist_xi"]) <= 1e-11
+        assert relerr(m.solver_state.z, o.z) <= 1e-11 and relerr(m.solver_state.v, o.v) <= 1e-11
+        z_flat = m.solver_state.z.copy()
+        m.close()
+        monkeypatch.setenv("SPOCK_AMD_FLAT_LOCAL", "0")
+        m0 = S.build_model(*specs, lib_path=emu, max_iter=40, **kw)
+        assert [n for n, _, _ in m0.profile_sequence(1)] == ["sub_a", "crown", "sub_b"]
+        m0.reset(); S.solve_model(m0, x0, tol=1e-12, verbose=S.LOG)
+        assert relerr(m0.solver_state.z, z_flat) <= 1e-13
+        m0.close()
+        monkeypatch.delenv("SPOCK_AMD_FLAT_LOCAL")
+        # SP: FLAT_A + sweeps + FLAT_B_SP per T evaluation
+        ms = S.build_model(*specs, S.SolverOptions(S.SP, None), lib_path=emu, max_iter=12, **kw)
+        S.solve_model(ms, x0, tol=1e-12, verbose=S.LOG)
+        os_ = O.Oracle(flat, O.SP); os_.L_norm = ms.solver_state.L_norm
+        rs = os_.solve(x0, tol=1e-12, verbose=O.LOG, max_iter=12, history=20)
+        hs = ms.history()
+        assert np.max(np.abs(hs["xi"] - rs["hist_xi"]) / rs["hist_xi"]) <= 1e-9 and np.array_equal(hs["backtrack"], rs["hist_backtrack"])
+        ms.close()
 
 
 def test_emulated_nan_and_state_api(S, O, emu):

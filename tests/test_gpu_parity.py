@@ -649,3 +649,24 @@ def test_bench_regime_matches_oracle(S, O):
             oracles[b].solve(x0[b], tol=0.0, max_iter=M)
             assert relerr(Z[b], oracles[b].z) <= 1e-9 and relerr(V[b], oracles[b].v) <= 1e-9, (step, b)
     m.close()
+
+
+def test_mpc_steps_chained_on_the_device(S, O, monkeypatch):
+    """The closed loop of examples/server_heat/mpc_simulation.jl:47-54,164-177 with its steps chained on the device (SP_CTL_M): per-step
+    iteration counts, statuses and trajectories identical to the host loop of solve calls (SPOCK_AMD_MPC_HOST=1) -- the instances
+    are independent and run the same kernels -- at nx = nu = 20 (flat node-local kernels + MFMA sweep levels) and at nx = 5."""
+    for specs, B, steps in ((S.get_server_heat_specs(7, 20, 2), 5, 6), (S.get_server_heat_specs(8, 5, 2), 9, 8)):
+        nx = S.flatten_problem(*specs).nx
+        w = np.stack([np.random.default_rng(seed).integers(0, 2, size=steps) for seed in range(B)]).astype(np.int32)
+        x0 = 0.1 * (1.0 + 0.07 * np.arange(B))[:, None] * np.cos(np.arange(nx))[None, :]
+        out = {}
+        for mode in ("chain", "host"):
+            monkeypatch.setenv("SPOCK_AMD_MPC_HOST", "1" if mode == "host" else "0")
+            m = S.build_model(*specs, S.SolverOptions(S.SP, None), batch=B)
+            xt, ut, res = S.mpc_simulation(m, x0, w, tol=1e-3)
+            out[mode] = (xt, ut, [[(r["iterations"], r["status"]) for r in rb] for rb in res], m.solver_state.z.copy())
+            m.close()
+        assert out["chain"][2] == out["host"][2] and all(st == 0 for rb in out["host"][2] for _, st in rb)
+        assert len({n for rb in out["host"][2] for n, _ in rb}) > 2            # instances stop at different iterations
+        for k in (0, 1, 3):
+            assert np.array_equal(out["chain"][k], out["host"][k])
