@@ -605,9 +605,12 @@ SPK_DEV void mfma_load_frags(real (&af)[KF], MPT Mx, long ld, int kq, int nk4, i
 // NXC / NUC / DC: compile-time nx / nu / d of the instantiation (64 / 16 / 2 for BASELINE config 5).  Work item = (row tile m,
 // share sp of the node tiles): the wave keeps the fragments of BOTH children's matrices for its row tile and sums over the
 // children in a fixed order, so the result does not depend on which wave ran when (bitwise repeatable).
-template <int NXC, int NUC, int DC, class P, class MPT>
+// SXP / SUP: stride (in elements) of a node's x-sized / u-sized vector in the LDS arrays XQ / ED / UL; sxl: that of XL.  The dedicated
+// sweep kernels (spock_skernels.hip) pad them by 4: with stride nx = 64 the 16 nodes of a tile sit 512 B apart and their operand
+// reads hit the same LDS banks (measured: a 64-node level 13.6 -> 8.5 us, a 16-node one 4.8 -> 4.1 us).
+template <int NXC, int NUC, int DC, int SXP = NXC, int SUP = NUC, class P, class MPT>
 SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, int cnt, bool kids_gleaf, int tid, int nthreads,
-                            const TeamLds &L) {
+                            const TeamLds &L, int sxl = NXC) {
     constexpr int nx = NXC, nu = NUC, d = DC, KQ = NXC / 4;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -629,32 +632,39 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
             const int pos = nt * 16 + j;
             const bool valid = pos < cnt;
             const int li = lvl_first + (valid ? pos : 0), posv = valid ? pos : 0;
-            spk_v4d acc = {0., 0., 0., 0.};
+            // one accumulator chain PER CHILD (independent matrix-core pipelines: the dependent chain is KQ long, not d * KQ),
+            // added in child order afterwards: bitwise repeatable
+            spk_v4d accc[DC];
 #pragma unroll
-            for (int c = 0; c < d; ++c) {
-                const real *qc = kids_gleaf ? L.XL + (long)(posv * d + c) * nx : L.XQ + (long)(li * d + 1 + c) * nx;
+            for (int c = 0; c < d; ++c) accc[c] = spk_v4d{0., 0., 0., 0.};
 #pragma unroll
-                for (int q = 0; q < KQ; ++q) {
+            for (int q = 0; q < KQ; ++q) {
+#pragma unroll
+                for (int c = 0; c < d; ++c) {
+                    const real *qc = kids_gleaf ? L.XL + (long)(posv * d + c) * sxl : L.XQ + (long)(li * d + 1 + c) * SXP;
                     const real bv = valid ? qc[4 * q + kq] : 0.;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][q], bv, acc, 0, 0, 0);
+                    accc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][q], bv, accc[c], 0, 0, 0);
                 }
             }
+            spk_v4d acc = accc[0];
+#pragma unroll
+            for (int c = 1; c < d; ++c) acc += accc[c];
             if (valid) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int r = row0 + kq + 4 * reg;
                     if (r >= nrow) continue;
-                    if (isq) L.XQ[(long)li * nx + r] += acc[reg];
-                    else L.ED[(long)li * nu + r] -= acc[reg];
+                    if (isq) L.XQ[(long)li * SXP + r] += acc[reg];
+                    else L.ED[(long)li * SUP + r] -= acc[reg];
                 }
             }
         }
     }
 }
 
-template <int NXC, int NUC, int DC, class P, class MPT>
+template <int NXC, int NUC, int DC, int SXP = NXC, int SUP = NUC, class P, class MPT>
 SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_first, int cnt, bool kids_gleaf, int tid, int nthreads,
-                            const TeamLds &L) {
+                            const TeamLds &L, int sxl = NXC) {
     constexpr int nx = NXC, nu = NUC, d = DC, KQ = NXC / 4, KU = NUC / 4;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -683,27 +693,32 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
             const int pos = nt * 16 + j;
             const bool valid = pos < cnt;
             const int li = lvl_first + (valid ? pos : 0), posv = valid ? pos : 0;
-            const real *xi = L.XQ + (long)li * nx, *di = L.ED + (long)li * nu;
-            spk_v4d acc = {0., 0., 0., 0.};
+            const real *xi = L.XQ + (long)li * SXP, *di = L.ED + (long)li * SUP;
+            // two independent accumulator chains over the even / odd k-steps of [ABK_c | K] x_i, a third for B_c d_i; added in a
+            // fixed order afterwards
+            spk_v4d acc = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.}, accb = {0., 0., 0., 0.};
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 const real bv = valid ? xi[4 * q + kq] : 0.;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bv, acc, 0, 0, 0);
+                if (q & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bv, acc1, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bv, acc, 0, 0, 0);
             }
+            acc += acc1;
             if (isx) {
 #pragma unroll
                 for (int q = 0; q < KU; ++q) {
                     const real bv = valid ? di[4 * q + kq] : 0.;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[q], bv, acc, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[q], bv, accb, 0, 0, 0);
                 }
+                acc += accb;
                 if (valid) {
-                    real *dst = kids_gleaf ? L.XL + (long)(posv * d + c) * nx : L.XQ + (long)(li * d + 1 + c) * nx;
+                    real *dst = kids_gleaf ? L.XL + (long)(posv * d + c) * sxl : L.XQ + (long)(li * d + 1 + c) * SXP;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) { const int r = row0 + kq + 4 * reg; if (r < nx) dst[r] = acc[reg]; }
                 }
             } else if (valid) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) { const int r = row0 + kq + 4 * reg; if (r < nu) L.UL[(long)li * nu + r] = acc[reg] + di[r]; }
+                for (int reg = 0; reg < 4; ++reg) { const int r = row0 + kq + 4 * reg; if (r < nu) L.UL[(long)li * SUP + r] = acc[reg] + di[r]; }
             }
         }
     }

@@ -43,6 +43,18 @@ SPK_DEV int group_threads_dev(int d, int stages) {   // non-leaf nodes of a comp
     return cnt;
 }
 
+// dst[k] = src[k], k < n, strided over the workgroup with four loads in flight per thread (a plain loop waits for every load before
+// its store: 18 dependent round trips when a 1024-thread crown copies its 18 k sweep inputs)
+template <class D, class S>
+SPK_DEV void wg_copy(D dst, S src, int n, int tid, int nthr) {
+    int k = tid;
+    for (; k + 3 * nthr < n; k += 4 * nthr) {
+        const real a0 = src[k], a1 = src[k + nthr], a2 = src[k + 2 * nthr], a3 = src[k + 3 * nthr];
+        dst[k] = a0; dst[k + nthr] = a1; dst[k + 2 * nthr] = a2; dst[k + 3 * nthr] = a3;
+    }
+    for (; k < n; k += nthr) dst[k] = src[k];
+}
+
 template <class P, int MODE_, class X>
 SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     constexpr int MODE = (MODE_ == MODE_SUB_B_SP || MODE_ == MODE_SUB_B_LAT) ? MODE_SUB_B : (MODE_ == MODE_FULL_SP) ? MODE_FULL : MODE_;
@@ -154,9 +166,14 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     TeamLds tl;
     tl.XQ = ex; tl.ED = tl.XQ + nl_grp * p.nx(); tl.UL = tl.ED + nl_grp * p.nu(); tl.XL = tl.UL + nl_grp * p.nu();
     real *lds_after_vectors = tl.XL + ngl_grp * p.nx();
+    // flat node-local kernels + group-leaf vector in global memory: that vector IS a region of global memory already -- zbar's own
+    // x entries of the group leaves (subtrees: q_leaf in, x_leaf out), the subtree roots' q in qroot (crown, on the way up)
+    const bool xl_direct = flat && a.xl_global && !crown_blk;
+    const long gl_first_x = dm.first[root_stage + stages - 1] + (long)root_pos * ngl_grp;
     if (a.xl_global) {   // the group-leaf vector in global memory (one slice per workgroup), everything else as before
         lds_after_vectors = tl.XL;
-        tl.XL = a.xlbuf + ((long)inst * n_groups + g) * a.xl_stride;
+        tl.XL = a.xlbuf + ((long)inst * (dm.nsub + 1) + g) * a.xl_stride;
+        if (xl_direct) tl.XL = (MODE == MODE_CROWN) ? a.qroot + (long)inst * dm.nsub * dm.nx : zo + dm.zx + gl_first_x * p.nx();
     }
 
     // register-resident variant of the team sweep: rows of this thread's node in registers, loaded before phase A so that
@@ -217,11 +234,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 for (int l = 0; l <= stages - 2; ++l) {
                     int lfirst, cnt; long gfirst;
                     level_geo(l, lfirst, cnt, gfirst);
-                    for (int k = tid; k < cnt * nx; k += nthr) tl.XQ[lfirst * nx + k] = zout[dm.zx + gfirst * nx + k];
-                    for (int k = tid; k < cnt * nu; k += nthr) tl.ED[lfirst * nu + k] = zout[dm.zu + gfirst * nu + k];
+                    wg_copy(tl.XQ + lfirst * nx, zout + dm.zx + gfirst * nx, cnt * nx, tid, nthr);
+                    wg_copy(tl.ED + lfirst * nu, zout + dm.zu + gfirst * nu, cnt * nu, tid, nthr);
                 }
-                const long gl_first = dm.first[root_stage + stages - 1] + (long)root_pos * ngl_grp;
-                for (int k = tid; k < ngl_grp * nx; k += nthr) tl.XL[k] = zout[dm.zx + gl_first * nx + k];
+                if (!xl_direct) wg_copy(tl.XL, zout + dm.zx + gl_first_x * nx, ngl_grp * nx, tid, nthr);
             });
             return;   // (backward() starts with a barrier)
         }
@@ -282,9 +298,9 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                             else if (k < st_n1 + st_n2) tl.XL[k - st_n1] = s.stg[j];
                         }
                     } else {
-                        for (int k = tid; k < nl_grp * nx; k += nthr) tl.XQ[k] = flat ? zo[dm.zx + k] : cb[k];
-                        for (int k = tid; k < nl_grp * nu; k += nthr) tl.ED[k] = flat ? zo[dm.zu + k] : cb[nl_grp * nx + k];
-                        for (int k = tid; k < ngl_grp * nx; k += nthr) tl.XL[k] = qg[k];
+                        wg_copy(tl.XQ, flat ? (const real *)(zo + dm.zx) : (const real *)cb, nl_grp * nx, tid, nthr);
+                        wg_copy(tl.ED, flat ? (const real *)(zo + dm.zu) : (const real *)(cb + nl_grp * nx), nl_grp * nu, tid, nthr);
+                        if (!xl_direct) wg_copy(tl.XL, qg, ngl_grp * nx, tid, nthr);
                     }
                 });
             }
@@ -336,7 +352,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     for (int l = 0; l <= stages - 2; ++l) {
                         int lfirst, cnt; long gfirst;
                         level_geo(l, lfirst, cnt, gfirst);
-                        for (int k = tid; k < cnt * nu; k += nthr) db[gfirst * nu + k] = tl.ED[lfirst * nu + k];
+                        wg_copy(db + gfirst * nu, tl.ED + lfirst * nu, cnt * nu, tid, nthr);
                     }
                 });
             }
@@ -380,6 +396,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
         if (team) {
             const real *lmB = lm + n_sw;
             const MatPtr gB = M + dm.mB;
+            if (xl_direct && MODE == MODE_CROWN) tl.XL = zo + dm.zx + gl_first_x * nx;   // on the way down: x of the subtree roots, in place
             x.each([&](int tid, TState<P> &s) {
                 if (tid < nx) tl.XQ[tid] = xroot[tid];
                 if (loads_d && staged) {
@@ -388,7 +405,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                     for (int l = 0; l <= stages - 2; ++l) {
                         int lfirst, cnt; long gfirst;
                         level_geo(l, lfirst, cnt, gfirst);
-                        for (int k = tid; k < cnt * nu; k += nthr) tl.ED[lfirst * nu + k] = db[gfirst * nu + k];
+                        wg_copy(tl.ED + lfirst * nu, db + gfirst * nu, cnt * nu, tid, nthr);
                     }
                 }
             });
@@ -432,11 +449,10 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
                 for (int l = 0; l <= stages - 2; ++l) {
                     int lfirst, cnt; long gfirst;
                     level_geo(l, lfirst, cnt, gfirst);
-                    for (int k = tid; k < cnt * nx; k += nthr) zo[dm.zx + gfirst * nx + k] = tl.XQ[lfirst * nx + k];
-                    for (int k = tid; k < cnt * nu; k += nthr) zo[dm.zu + gfirst * nu + k] = tl.UL[lfirst * nu + k];
+                    wg_copy(zo + dm.zx + gfirst * nx, tl.XQ + lfirst * nx, cnt * nx, tid, nthr);
+                    wg_copy(zo + dm.zu + gfirst * nu, tl.UL + lfirst * nu, cnt * nu, tid, nthr);
                 }
-                const long gl_first = dm.first[root_stage + stages - 1] + (long)root_pos * ngl_grp;
-                for (int k = tid; k < ngl_grp * nx; k += nthr) zo[dm.zx + gl_first * nx + k] = tl.XL[k];
+                if (!xl_direct) wg_copy(zo + dm.zx + gl_first_x * nx, tl.XL, ngl_grp * nx, tid, nthr);
                 if (s.active && !team_local) {
                     for (int k = 0; k < nx; ++k) s.xb[k] = tl.XQ[tid * nx + k];
                     for (int k = 0; k < nu; ++k) s.ub[k] = tl.UL[tid * nu + k];

@@ -98,6 +98,8 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
 
 
 int launch_flat_local(int mode, const KArgs &a, void *stream);   // flat node-local kernels (spock_fkernels.hip)
+bool sweep_kernels_apply(const Dims &dm);                         // dedicated matrix-core sweep kernels (spock_skernels.hip)
+int launch_sweep(int mode, const KArgs &a, void *stream);
 
 bool have_static_variant(int nx, int nu, int d, int ny) {
 #define X(a, b, c, e) if (nx == a && nu == b && d == c && ny == e) return true;
@@ -113,6 +115,8 @@ int launch_group(int mode, const KArgs &a, void *stream) {
     static const bool force_dyn = std::getenv("SPOCK_AMD_FORCE_DYN") != nullptr;   // experiments: run-time-dimension kernels for every shape
     if (a.ilv) return launch_igroup(mode, a, stream);   // element-major batched regime (spock_ikernels.hip)
     if (mode >= MODE_FLAT_A && mode <= MODE_FLAT_BA) return launch_flat_local(mode, a, stream);   // spock_fkernels.hip
+    if (a.flat_local && cm == 2 && (mode == MODE_SUB_A || mode == MODE_CROWN || mode == MODE_SUB_B) && sweep_kernels_apply(dm))
+        return launch_sweep(mode, a, stream);                                                      // spock_skernels.hip
 #define X(a_, b_, c_, e_)                                                                      \
     if (!force_dyn && dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                  \
         return cm == 2 ? launch_variant<StaticDims<a_, b_, c_, e_, 2>>(mode, a, st) : cm == 1 ? launch_variant<StaticDims<a_, b_, c_, e_, 1>>(mode, a, st)    \
