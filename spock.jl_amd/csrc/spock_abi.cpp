@@ -449,10 +449,9 @@ int launch_sp_iteration(spock_handle_s *h) {
 int sp_init_state(spock_handle_s *h) {
     const Dims &dm = h->bp.dm;
     const size_t B = (size_t)h->batch, nr = (size_t)dm.nz + dm.nv;
-    for (int k = 0; k < 10; ++k) { int e = rt::dzero(h->s_vec[k], B * nr * sizeof(real), h->stream); if (e) return e; }
+    for (int k = 0; k < 10; ++k) { if (!h->s_vec[k]) continue; int e = rt::dzero(h->s_vec[k], B * nr * sizeof(real), h->stream); if (e) return e; }
     std::vector<double> ones(B * nr, 1.0);
-    int e = up(h, h->s_vec[SV_ZOLD], ones.data(), B * nr);
-    if (!e) e = up(h, h->s_vec[SV_ROLD], ones.data(), B * nr);
+    int e = up(h, h->s_vec[SV_ROLD], ones.data(), B * nr);   // rz_old = rv_old = 1 (models/spock.jl:159-201); z_old itself is not stored (spock_sp.hpp: FLAT5)
     if (!e) e = rt::sync(h->stream);
     if (!e) e = rt::dzero(h->s_MP, B * 3 * nr * sizeof(real), h->stream);
     if (!e) e = rt::dzero(h->s_Q, B * 3 * nr * sizeof(real), h->stream);
@@ -777,7 +776,10 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
             h->lat_regime = dm.t0 > 0 && launch_geometry(MODE_SUB_B, dm, h->batch).team_reg != 0;
     } else {
         const size_t nr = (size_t)dm.nz + dm.nv;
-        for (int k = 0; k < 10; ++k) if ((e = dev_alloc(h, &h->s_vec[k], B * nr))) return bail(e, "hipMalloc(SP state)");
+        for (int k = 0; k < 10; ++k) {
+            if (k == SV_ZOLD || (k == SV_RW && !std::getenv("SPOCK_AMD_SP_LOP"))) continue;   // not stored (FLAT5) / only the separate-LOP sequence forms rt = w - wbar
+            if ((e = dev_alloc(h, &h->s_vec[k], B * nr))) return bail(e, "hipMalloc(SP state)");
+        }
         if ((e = dev_alloc(h, &h->s_MP, B * 3 * nr)) || (e = dev_alloc(h, &h->s_Q, B * 3 * nr)) ||
             (e = dev_alloc(h, &h->s_partF, B * (size_t)sp_flat_blocks((long)nr) * kSpSums)) ||
             (e = dev_alloc(h, &h->s_partL, B * (size_t)sp_lop_blocks(dm) * kSpSums)) || (e = dev_alloc(h, &h->s_ctl, B)))

@@ -585,11 +585,20 @@ SPK_DEV void fwd_level_team(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
 // Rounding: the order of summation over k differs from the scalar sweeps (parity is checked at 1e-12 relative).
 #ifndef SPOCK_HOST_EMU
 typedef double spk_v4d __attribute__((ext_vector_type(4)));
+typedef float spk_v4f __attribute__((ext_vector_type(4)));
+// One 16 x 16 x 4 matrix-core step in the precision of `real`: v_mfma_f64_16x16x4_f64 in libspock_amd.so, v_mfma_f32_16x16x4_f32 in
+// libspock_amd_f32.so (BASELINE config 5's fp32 leg then runs its sweep levels on the matrix cores too).  A[i = lane & 15][k = lane >> 4]
+// and B[k = lane >> 4][j = lane & 15] are laid out alike; the accumulator's rows are not: register `reg` of a lane holds row
+// (lane >> 4) + 4 reg (f64) or 4 (lane >> 4) + reg (f32) of column lane & 15 (cdna_hip_programming.md section 3).
+typedef real spk_vacc __attribute__((ext_vector_type(4)));
+SPK_DEV spk_v4d spk_mfma(double a, double b, spk_v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+SPK_DEV spk_v4f spk_mfma(float a, float b, spk_v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+SPK_DEV constexpr int spk_mfma_row(int kq, int reg) { return kRealIsDouble ? kq + 4 * reg : 4 * kq + reg; }
 
 // instantiated shapes (nx, nu, d): BASELINE config 5 (64, 16, 2), config 4 (20, 20, 2) and config 3 (20, 20, 3) -- for nx = nu = 20
 // the row tiles are padded to 16 and the rows past nx / nu masked
 SPK_DEV bool mfma_sweep_applies(int nx, int nu, int d) {
-    return kRealIsDouble && ((nx == 64 && nu == 16 && d == 2) || (nx == 20 && nu == 20 && (d == 2 || d == 3)));
+    return (nx == 64 && nu == 16 && d == 2) || (nx == 20 && nu == 20 && (d == 2 || d == 3));
 }
 
 // One wave owns a ROW tile m of the level's product and keeps its matrix fragments (KF k-steps: one 8-byte element per lane
@@ -634,25 +643,25 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
             const int li = lvl_first + (valid ? pos : 0), posv = valid ? pos : 0;
             // one accumulator chain PER CHILD (independent matrix-core pipelines: the dependent chain is KQ long, not d * KQ),
             // added in child order afterwards: bitwise repeatable
-            spk_v4d accc[DC];
+            spk_vacc accc[DC];
 #pragma unroll
-            for (int c = 0; c < d; ++c) accc[c] = spk_v4d{0., 0., 0., 0.};
+            for (int c = 0; c < d; ++c) accc[c] = spk_vacc{0., 0., 0., 0.};
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
 #pragma unroll
                 for (int c = 0; c < d; ++c) {
                     const real *qc = kids_gleaf ? L.XL + (long)(posv * d + c) * sxl : L.XQ + (long)(li * d + 1 + c) * SXP;
                     const real bv = valid ? qc[4 * q + kq] : 0.;
-                    accc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][q], bv, accc[c], 0, 0, 0);
+                    accc[c] = spk_mfma(af[c][q], bv, accc[c]);
                 }
             }
-            spk_v4d acc = accc[0];
+            spk_vacc acc = accc[0];
 #pragma unroll
             for (int c = 1; c < d; ++c) acc += accc[c];
             if (valid) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int r = row0 + kq + 4 * reg;
+                    const int r = row0 + spk_mfma_row(kq, reg);
                     if (r >= nrow) continue;
                     if (isq) L.XQ[(long)li * SXP + r] += acc[reg];
                     else L.ED[(long)li * SUP + r] -= acc[reg];
@@ -696,29 +705,29 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
             const real *xi = L.XQ + (long)li * SXP, *di = L.ED + (long)li * SUP;
             // two independent accumulator chains over the even / odd k-steps of [ABK_c | K] x_i, a third for B_c d_i; added in a
             // fixed order afterwards
-            spk_v4d acc = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.}, accb = {0., 0., 0., 0.};
+            spk_vacc acc = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.}, accb = {0., 0., 0., 0.};
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 const real bv = valid ? xi[4 * q + kq] : 0.;
-                if (q & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bv, acc1, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bv, acc, 0, 0, 0);
+                if (q & 1) acc1 = spk_mfma(af[q], bv, acc1);
+                else acc = spk_mfma(af[q], bv, acc);
             }
             acc += acc1;
             if (isx) {
 #pragma unroll
                 for (int q = 0; q < KU; ++q) {
                     const real bv = valid ? di[4 * q + kq] : 0.;
-                    accb = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[q], bv, accb, 0, 0, 0);
+                    accb = spk_mfma(bf[q], bv, accb);
                 }
                 acc += accb;
                 if (valid) {
                     real *dst = kids_gleaf ? L.XL + (long)(posv * d + c) * sxl : L.XQ + (long)(li * d + 1 + c) * SXP;
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) { const int r = row0 + kq + 4 * reg; if (r < nx) dst[r] = acc[reg]; }
+                    for (int reg = 0; reg < 4; ++reg) { const int r = row0 + spk_mfma_row(kq, reg); if (r < nx) dst[r] = acc[reg]; }
                 }
             } else if (valid) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) { const int r = row0 + kq + 4 * reg; if (r < nu) L.UL[(long)li * SUP + r] = acc[reg] + di[r]; }
+                for (int reg = 0; reg < 4; ++reg) { const int r = row0 + spk_mfma_row(kq, reg); if (r < nu) L.UL[(long)li * SUP + r] = acc[reg] + di[r]; }
             }
         }
     }

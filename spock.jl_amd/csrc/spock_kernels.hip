@@ -125,7 +125,7 @@ int launch_group(int mode, const KArgs &a, void *stream) {
 #undef X
     if (cm == 2 && launch_geometry(mode == MODE_FINALIZE ? MODE_CROWN : mode, dm, a.batch).team_local) {
         static const bool no_mfma = std::getenv("SPOCK_AMD_NO_MFMA") != nullptr;
-        if (((dm.nx == 64 && dm.nu == 16 && dm.d == 2) || (dm.nx == 20 && dm.nu == 20 && (dm.d == 2 || dm.d == 3))) && !no_mfma && kRealIsDouble)
+        if (((dm.nx == 64 && dm.nu == 16 && dm.d == 2) || (dm.nx == 20 && dm.nu == 20 && (dm.d == 2 || dm.d == 3))) && !no_mfma)
             return launch_variant<DynDims<2, true, true>>(mode, a, st);   // MFMA sweep levels (BASELINE configs 5, 4 and 3)
         return launch_variant<DynDims<2, true>>(mode, a, st);
     }

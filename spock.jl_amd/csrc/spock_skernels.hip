@@ -238,10 +238,10 @@ static int launch_sweep_shape(int mode, const KArgs &a_in, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// true when the dedicated sweep kernels exist for this problem (flat node-local kernels + a matrix-core shape, fp64)
+// true when the dedicated sweep kernels exist for this problem (flat node-local kernels + a matrix-core shape; either precision)
 bool sweep_kernels_apply(const Dims &dm) {
     static const bool off = std::getenv("SPOCK_AMD_NO_SWEEPK") != nullptr || std::getenv("SPOCK_AMD_NO_MFMA") != nullptr;
-    if (off || !kRealIsDouble || dm.t0 <= 0) return false;
+    if (off || dm.t0 <= 0) return false;
     return (dm.nx == 64 && dm.nu == 16 && dm.d == 2) || (dm.nx == 20 && dm.nu == 20 && (dm.d == 2 || dm.d == 3));
 }
 

@@ -47,8 +47,7 @@ SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, dou
             a.R[o] = r;
             p1[e] = a.DP[o] - dr;                 // MP[:,1] = delta_p - delta_r   (anderson.jl:25-32)
             q1[e] = dr;                           // Q[:,1]  = MR[:,1] = delta_r   (anderson.jl:63-65)
-            a.ROLD[o] = r;                        // update_sy! (sp.jl:232-255)
-            a.ZOLD[o] = z;
+            a.ROLD[o] = r;                        // update_sy! (sp.jl:232-255); z_old <- z needs no copy: see FLAT5
             const real b = q2[e], cc = q3[e];
             sums[0] += dr * dr; sums[1] += b * dr; sums[2] += cc * dr; sums[3] += b * b; sums[4] += cc * cc; sums[5] += b * cc;
             sums[6] += dr * r; sums[7] += b * r; sums[8] += cc * r;      // MR'r: right-hand side of the corrected variant's normal equations
@@ -73,12 +72,15 @@ SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, dou
             a.RW[o] = a.W[o] - a.WB[o];                              // sp.jl:155-160
             break;
         case SP_FLAT5: {
-            real z = a.Z[o];
+            // z_old of update_sy! (sp.jl:232-255) is the iterate this iteration started from -- still in Z here, nothing has written Z since
+            // FLAT1 -- so delta_z = z_new - z_old needs no stored copy (one vector written and one read less per iteration)
+            const real z_old = a.Z[o];
+            real z = z_old;
             if (c.accept == 1) z = a.W[o];                           // K1 (sp.jl:166-191)
             else if (c.accept == 2) z -= c.coef * (a.fused_lop ? a.W[o] - a.WB[o] : a.RW[o]);   // K2 (sp.jl:193-222); rt = w - wbar (:155-160)
             else z = a.ZB[o];                                        // plain CP step (sp.jl:443-446)
             a.Z[o] = z;
-            a.DP[o] = z - a.ZOLD[o];                                 // delta_z / delta_v (sp.jl:279-284)
+            a.DP[o] = z - z_old;                                     // delta_z / delta_v (sp.jl:279-284)
         } break;
         default: break;
     }
