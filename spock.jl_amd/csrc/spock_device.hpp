@@ -30,8 +30,10 @@
 #endif
 #ifdef SPOCK_HOST_EMU
 #define SPK_UNROLL4
+#define SPK_UNROLL8
 #else
 #define SPK_UNROLL4 _Pragma("unroll 4")   // run-time trip counts: keep four independent loads in flight
+#define SPK_UNROLL8 _Pragma("unroll 8")   // ... eight: rows of the small per-stage matrices fetched from L2 inside a mat-vec loop
 #endif
 
 namespace spock {

@@ -335,6 +335,11 @@ SPK_DEV void fb_child_v2(const P &p, const Dims &dm, MatPtr M, const real *__res
     if (r == 0) out[c] = ps.sigma * (t2 - (t2 >= 0. ? t2 : 0.));
 }
 
+// matrices a workgroup's phase A needs, staged in LDS behind the teams' scratch: U_t (nx x nu) and Rt^-1_t (nu x nu) of the stage of
+// the workgroup's FIRST node -- consecutive nodes share a stage except across a stage boundary, where the odd node fetches its rows
+// from the pool -- and the S2 projector when all nodes share one (m x m)
+SPK_DEV int flat_mats_doubles(int nx, int nu, int m) { return nx * nu + nu * nu + m * m; }
+
 // scratch of one team: [vec: m][ubar: nu][vbar.v2 of the children: d] (+ host emulation: [red: (2 + 3 d) T])
 SPK_DEV int flat_scratch_doubles(int nu, int m, int d, int T) {
 #ifdef SPOCK_HOST_EMU
@@ -377,6 +382,21 @@ SPK_DEV void flat_body(X &x, const KArgs &a, int inst, int g) {
 
     // ---- phase A of the team's node on the iterate (zi, vi): its part of the next zbar (y_i, s / tau of the children, s_1) to zn,
     //      c_i -> zn.x_i, e_i -> zn.u_i, q_leaf = -xbar_leaf -> zn.x_leaf
+    real *lmat = scr + nteams * stride;                  // [U_t | Rt^-1_t | LS] of the stage of the workgroup's first node
+    const int stage0 = flat_team_node(dm, d, node0).stage;
+    auto stage_mats = [&]() SPK_LAMBDA_INLINE {          // issued first thing: one coalesced copy, overlapping the node loads of part 1
+        x.each([&](int tid, TState<P> &) {
+            const real *sU = a.mats + dm.mU + (long)stage0 * nx * nu, *sR = a.mats + dm.mRinv + (long)stage0 * nu * nu, *sL = a.mats + dm.mLs;
+            for (int k = tid; k < nx * nu; k += nthr) lmat[k] = sU[k];
+            for (int k = tid; k < nu * nu; k += nthr) lmat[nx * nu + k] = sR[k];
+            if (dm.nRm <= 1) for (int k = tid; k < m * m; k += nthr) lmat[nx * nu + nu * nu + k] = sL[k];
+        });
+    };
+#ifndef FLAT_EXP
+#define FLAT_EXP 0
+#endif
+    if (FLAT_EXP == 1 && MODE_ == MODE_FLAT_A) return;                       // experiment: launch + control only
+    if (MODE_ == MODE_FLAT_A || MODE_ == MODE_FLAT_BA) stage_mats();
     auto phase_a = [&](const real *zi, const real *vi, real *zn, bool use_v2x) SPK_LAMBDA_INLINE {
         x.each([&](int tid, TState<P> &s) {
             const int tm = tid / T, r = tid - tm * T;
@@ -386,13 +406,16 @@ SPK_DEV void flat_body(X &x, const KArgs &a, int inst, int g) {
             const real *v2x = (use_v2x && !tn.kids_leaf) ? v2x_of(tm) : nullptr;
             ta_p1(p, dm, M, zi, vi, zn, tn, r, T, S_of(tm), zn + dm.zx + (long)tn.c0 * nx, gamma, flags & ~F_RAW_LT, s.tlr, v2x);
         });
-        x.team_sync();
+        if (FLAT_EXP == 2 && MODE_ == MODE_FLAT_A) return;                   // experiment: part 1 only
+        x.barrier();    // the staged matrices come from every wave of the workgroup
         x.each([&](int tid, TState<P> &s) {
             const int tm = tid / T, r = tid - tm * T;
             if (tm >= nteams) return;
             const TeamNode tn = flat_team_node(dm, d, node0 + tm);
             if (!tn.active) return;
-            ta_p2(p, dm, M, zn, tn, r, T, S_of(tm), zn + dm.zx + (long)tn.node * nx, zn + dm.zu + (long)tn.node * nu, s.tlr);
+            const bool st = (tn.stage == stage0);
+            ta_p2(p, dm, M, zn, tn, r, T, S_of(tm), zn + dm.zx + (long)tn.node * nx, zn + dm.zu + (long)tn.node * nu, s.tlr,
+                  st ? lmat : nullptr, st ? lmat + nx * nu : nullptr, dm.nRm <= 1 ? lmat + nx * nu + nu * nu : nullptr);
         });
     };
 

@@ -234,7 +234,7 @@ FlatGeo flat_geometry(const Dims &dm) {
     g.chunks = (dm.nn + g.nteams - 1) / g.nteams;
     const int m = dm.ny + 2 * dm.d;
     // per team: flat_scratch_doubles, sized for the host emulation's extra rows too (the GPU uses the first m + nu + d doubles)
-    g.ex_doubles = g.nteams * (m + dm.nu + dm.d + (2 + 3 * dm.d) * T);
+    g.ex_doubles = g.nteams * (m + dm.nu + dm.d + (2 + 3 * dm.d) * T) + (dm.nx * dm.nu + dm.nu * dm.nu + m * m);   // + the staged U_t, Rt^-1_t, LS (flat_mats_doubles)
     g.lds_bytes = (size_t)g.ex_doubles * 8 + (4 + 128 + 64) * 8;          // + the reduction scratch / stamps / SP sums of the group kernels' carve
     return g;
 }

@@ -219,7 +219,15 @@ static int launch_sweep_shape(int mode, const KArgs &a_in, hipStream_t st) {
     }
     a.ex_doubles = (int)need;
     const size_t lds = (size_t)(a.ex_doubles + tail) * 8;
-    const dim3 grid(sw == SW_CROWN ? 1 : dm.nsub, a.batch), block(kSweepThreads);
+    // workgroup size: 16 waves when few workgroups are in flight (every row tile and node-tile share of a level gets a wave of its own);
+    // 4 or 8 when a batch fills the chip with workgroups anyway -- the narrow levels of a sweep have 4 - 8 row-tile tasks, and smaller
+    // workgroups let a CU interleave more of these latency-bound level chains
+    int threads = kSweepThreads;
+    const long wgs = (long)a.batch * (sw == SW_CROWN ? 1 : dm.nsub);
+    if (NX <= 32 && wgs >= 1024) threads = 256;
+    else if (NX <= 32 && wgs >= 256) threads = 512;
+    if (const char *e = std::getenv("SPOCK_AMD_SWEEP_THREADS")) { threads = std::atoi(e); if (threads < 64) threads = 64; if (threads > 1024) threads = 1024; threads = (threads / 64) * 64; }
+    const dim3 grid(sw == SW_CROWN ? 1 : dm.nsub, a.batch), block(threads);
     static bool raised[16][3] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;

@@ -94,32 +94,38 @@ SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const real *__restrict_
 }
 
 // phase A, part 2: S2 projector rows, c_i = U ubar - xbar, e_i = Rt^-1 ubar
+// lmU / lmRi / lmLS: the stage's U_t, Rt^-1_t and the S2 projector staged in LDS by the caller (flat kernels: one coalesced copy per
+// workgroup), or nullptr -> rows fetched from the matrix pool element by element (eight loads in flight: without the unrolling every
+// iteration of these mat-vec loops waits for its own load, nu dependent round trips to L2 per node)
+template <class MP, class VP>
+SPK_DEV real tl_rowdot(MP row, int stride, VP vec, int n) {
+    real a = 0.;
+    SPK_UNROLL8 for (int k = 0; k < n; ++k) a += row[(long)k * stride] * vec[k];
+    return a;
+}
 template <class P>
 SPK_DEV void ta_p2(const P &p, const Dims &dm, MatPtr M, real *__restrict__ zo, const TeamNode &t, int r, int T,
-                   const real *S, real *cq, real *ce, const TLReg<P> &g) {
+                   const real *S, real *cq, real *ce, const TLReg<P> &g, const real *lmU = nullptr, const real *lmRi = nullptr,
+                   const real *lmLS = nullptr) {
     if (!t.active) return;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), m = ny + 2 * d;
     const int i = t.node;
     const real *vec = S, *ubs = S + m;
     const MatPtr LS = M + dm.mLs + (dm.nRm > 1 ? i * m * m : 0);
     for (int e = r; e < m; e += T) {   // implicit_l.jl:708-726
-        real a = 0.;
-        for (int k = 0; k < m; ++k) a += LS[e + k * m] * vec[k];
+        const real a = lmLS ? tl_rowdot(lmLS + e, m, vec, m) : tl_rowdot(LS + e, m, vec, m);
         if (e < ny) zo[dm.zy + i * ny + e] = a;
         else if (e < ny + d) zo[dm.zs + t.c0 + (e - ny)] = a;
         else zo[dm.zt + t.c0 + (e - ny - d) - 1] = a;
     }
     if (r < nx) {
         const MatPtr Ut = M + dm.mU + t.stage * nx * nu;
-        real a = 0.;
-        for (int k = 0; k < nu; ++k) a += Ut[r + k * nx] * ubs[k];
+        const real a = lmU ? tl_rowdot(lmU + r, nx, ubs, nu) : tl_rowdot(Ut + r, nx, ubs, nu);
         cq[r] = a - g.xb;
     }
     if (r < nu) {
         const MatPtr Ri = M + dm.mRinv + t.stage * nu * nu;
-        real a = 0.;
-        for (int k = 0; k < nu; ++k) a += Ri[r + k * nu] * ubs[k];
-        ce[r] = a;
+        ce[r] = lmRi ? tl_rowdot(lmRi + r, nu, ubs, nu) : tl_rowdot(Ri + r, nu, ubs, nu);
     }
 }
 
