@@ -446,26 +446,38 @@ def main(argv=None):
             # BASELINE config 5 (random linear nx = 64, nu = 16, N = 15, 16 384 leaves): the S1 sweep levels run on the fp64
             # matrix cores (v_mfma_f64_16x16x4_f64).  Flops per CP iteration from SURVEY.md section 8d.
             if args.tree_N >= 13:
+                # BASELINE config 5 (random linear nx = 64, nu = 16, N = 15, 16 384 leaves), one instance, both precisions: flat node-local
+                # kernels + sweep levels on the matrix cores (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).  Two rooflines per
+                # precision: flops per CP iteration (SURVEY.md 8d's count, diagonal cost roots) against the dense matrix-core peak, and
+                # SURVEY 8d's bytes_CP against the HBM peak.  A single instance is bound by neither: it is a chain of 2 x 14 dependent tree
+                # levels and five launch boundaries.
                 sp5 = S.get_random_linear_specs(15, 64, 16)
                 f5 = S.flatten_problem(*sp5)
-                mc = S.build_model(*sp5, S.SolverOptions(S.CP, None), batch=1, device=dev_index, max_iter=60, graph_iters=60, L_norm="auto")
-                xc = 0.1 * np.cos(np.arange(64))
-                S.solve_model(mc, xc, tol=0.0)
-                rc = S.solve_model(mc, xc, tol=0.0)
-                mc.close()
                 nn5, n5, nl5, ny5, dd = f5.nn, f5.n, f5.nl, f5.ny, f5.d
                 l_mac = nn5 * ny5 + (n5 - 1) * (64 + 16) + nl5 * 64                       # diagonal cost roots
                 s1_mac = nn5 * (16 * 16 + 2 * 64 * 16 + dd * (3 * 64 * 64 + 3 * 64 * 16))
                 s2_mac = nn5 * (ny5 + 2 * dd) ** 2
                 flops = 2.0 * (4 * l_mac + s1_mac + s2_mac)
-                ms_it = rc["solve_ms"] / rc["iterations"]
-                FP64_PEAK = 78.6   # TFLOP/s: AMD's public fp64 figure for MI355X (vector = matrix rate), as SURVEY.md 8d has it; the local guide gives none
-                out["cfg5"] = {"workload": "random linear nx=64 nu=16 d=2 N=15 (16384 leaves), one instance, CP", "ms_per_iteration": round(ms_it, 4),
-                               "flops_per_iteration": flops,
-                               "roofline": {"bound": "mfma", "kernel": "S1 sweep levels on v_mfma_f64_16x16x4_f64 (bwd_level_mfma / fwd_level_mfma)",
-                                            "achieved": round(flops / (ms_it * 1e-3) / 1e12, 3), "peak": FP64_PEAK, "unit": "TFLOP/s",
-                                            "frac": round(flops / (ms_it * 1e-3) / 1e12 / FP64_PEAK, 4), "traffic": None,
-                                            "note": "a single instance: bound by the chain of 2 x 14 dependent tree levels and two launch boundaries, not by either roofline"}}
+                PEAKS = {"f64": 78.6, "f32": 157.3}   # TFLOP/s dense matrix-core peaks (AMD's public MI355X figures; SURVEY.md 8d quotes the fp64 one)
+                out["cfg5"] = {"workload": "random linear nx=64 nu=16 d=2 N=15 (16384 leaves), one instance, CP", "flops_per_iteration": flops}
+                xc = 0.1 * np.cos(np.arange(64))
+                for dt in ("f64", "f32"):
+                    W = 8 if dt == "f64" else 4
+                    mc = S.build_model(*sp5, S.SolverOptions(S.CP, None), batch=1, device=dev_index, max_iter=60, graph_iters=60, L_norm="auto", dtype=dt)
+                    S.solve_model(mc, xc, tol=0.0)
+                    rc = S.solve_model(mc, xc, tol=0.0)
+                    seq5 = mc.profile_sequence(12)
+                    mc.close()
+                    ms_it = rc["solve_ms"] / rc["iterations"]
+                    b8d = W * (6 * f5.nz + 5 * f5.nv + 2 * (f5.n * f5.nx + f5.nn * f5.nu))
+                    out["cfg5"][dt] = {"ms_per_iteration": round(ms_it, 4), "launches_ms": [[n, round(ms, 5)] for n, _, ms in seq5],
+                                       "roofline_mfma": {"bound": "mfma", "achieved": round(flops / (ms_it * 1e-3) / 1e12, 3), "peak": PEAKS[dt], "unit": "TFLOP/s",
+                                                         "frac": round(flops / (ms_it * 1e-3) / 1e12 / PEAKS[dt], 4)},
+                                       "roofline_hbm": {"bound": "hbm", "achieved": round(b8d / (ms_it * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                        "frac": round(b8d / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_model": "SURVEY 8d bytes_CP", "bytes_per_iteration": b8d}}
+                out["cfg5"]["ms_per_iteration"] = out["cfg5"]["f64"]["ms_per_iteration"]
+                out["cfg5"]["roofline"] = dict(out["cfg5"]["f64"]["roofline_mfma"], kernel="S1 sweep levels on v_mfma_f64_16x16x4_f64 (spock_skernels.hip), node-local phases as flat kernels",
+                                               traffic=None, note="a single instance: a chain of 2 x 14 dependent tree levels and five launch boundaries; see f64 / f32 for both rooflines")
             # problems/s: 64 independent instances of the convergent (nu = 5) tree, different x0, solved to tol 1e-3 as one batch
             probs = {}
             X = 0.1 * (1.0 + 0.01 * np.arange(64))[:, None] * np.ones((64, NX))
@@ -489,6 +501,26 @@ def main(argv=None):
                 probs["cp_large_batch"] = {"instances": B, "layout": "element-major" if mb.sizes.interleaved else "instance-major",
                                            "ms": round(dtb * 1e3, 2), "problems_per_s": round(B / dtb, 1),
                                            "iterations_max": max(q["iterations"] for q in rb), "iterations_min": min(q["iterations"] for q in rb)}
+                mb.close()
+                # the Spock algorithm proper in the same batched regime (instance-major: its traffic is dominated by the Anderson vectors,
+                # which are layout-independent streams) with its roofline on SURVEY 8d's bytes_SP = 2 bytes_T + 26 W (nz + nv)
+                mb = S.build_model(*specs5, S.SolverOptions(S.SP, None), batch=B, device=dev_index)
+                S.solve_model(mb, XB, tol=1e-3); mb.reset()
+                torch.cuda.synchronize(); t = time.perf_counter(); rb = S.solve_model(mb, XB, tol=1e-3); torch.cuda.synchronize()
+                dtb = time.perf_counter() - t
+                assert all(q["status"] == 0 for q in rb)
+                it_max = max(q["iterations"] for q in rb)
+                W8 = 8
+                bytes_T = W8 * (4 * flat5.nz + 3 * flat5.nv + 2 * (flat5.n * flat5.nx + flat5.nn * flat5.nu))
+                bytes_SP = 2 * bytes_T + 26 * W8 * (flat5.nz + flat5.nv)
+                ms_it = rb[0]["solve_ms"] / it_max
+                probs["sp_large_batch"] = {"instances": B, "layout": "element-major" if mb.sizes.interleaved else "instance-major",
+                                           "ms": round(dtb * 1e3, 2), "problems_per_s": round(B / dtb, 1), "iterations_max": it_max,
+                                           "iterations_min": min(q["iterations"] for q in rb), "ms_per_batch_iteration": round(ms_it, 3),
+                                           "roofline": {"bound": "hbm", "bytes_model": "SURVEY 8d bytes_SP per instance-iteration", "bytes_per_instance_iteration": bytes_SP,
+                                                        "achieved": round(B * bytes_SP / (ms_it * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                        "frac": round(B * bytes_SP / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                        "note": "instances retire lane by lane over the solve, so the full batch moves fewer bytes than B x bytes_SP in the late iterations: an upper estimate"}}
                 mb.close()
             out["problems_to_tol_1e-3_nu5"] = probs
 

@@ -104,3 +104,57 @@ if bottom:
     out["per_kind_table"] = sorted(table, key=lambda t: -(t["avg_ms"] or 0) * t["launches_per_iteration"])
 json.dump(out, open(os.path.join(dst, f"pmc_b{B}_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+# ---- BASELINE config 5 (one instance, tools/prof_flat64.py 1 cfg5) and config 4's 64 closed loops: kernel stats + counters --------
+def _condense_aux():
+    import re
+    def short(name):
+        name = re.sub(r"spock::|void ", "", name)
+        m = re.match(r"(spock_\w+)<(.*)>\(", name)
+        return f"{m.group(1)}<{m.group(2)}>" if m else name.split("(")[0]
+    for tag in ("cfg5", "mpc64"):
+        st = os.path.join(dst, f"{tag}_kernel_stats.csv")
+        if not RECOMPUTE:
+            cands = glob.glob(os.path.join(src, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
+            if not cands:
+                continue
+            shutil.copy(max(cands, key=os.path.getmtime), st)
+        if not os.path.exists(st):
+            continue
+        kern = {}
+        for r in csv.DictReader(open(st)):
+            if "spock" in r["Name"]:
+                kern[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": round(float(r["AverageNs"]) / 1e6, 5), "pct": float(r["Percentage"])}
+        summ = {"workload": "BASELINE config 5: random linear nx=64 nu=16 N=15, one instance, 12 CP iterations" if tag == "cfg5"
+                else "BASELINE config 4: 64 closed-loop simulations x 20 steps, SP, tol 1e-3 (steps chained on the device)", "kernels": kern, "lib_sha16": _h}
+        for ctr, sub in (("FETCH_SIZE", f"{tag}_pmc_fetch"), ("WRITE_SIZE", f"{tag}_pmc_write")):
+            f = os.path.join(dst, f"{sub}_counter_collection.csv")
+            if not RECOMPUTE:
+                cands = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+                if not cands:
+                    continue
+                rows = [r for r in csv.DictReader(open(max(cands, key=os.path.getmtime))) if "spock" in r["Kernel_Name"]]
+                with open(f, "w", newline="") as g:
+                    w = csv.DictWriter(g, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+            if not os.path.exists(f):
+                continue
+            acc = {}
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == ctr:
+                    acc.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+            for k, v in acc.items():
+                kern.setdefault(k, {})[f"{ctr}_KB_mean"] = sum(v) / len(v)
+        tot_ms = tot_b = 0.0
+        for k, e in kern.items():
+            if "FETCH_SIZE_KB_mean" in e and "WRITE_SIZE_KB_mean" in e:
+                e["hbm_bytes_per_launch_corrected"] = int((2 * e["FETCH_SIZE_KB_mean"] + e["WRITE_SIZE_KB_mean"]) * 1024)   # FETCH_SIZE x 2 on gfx950
+                e["achieved_TBps"] = round(e["hbm_bytes_per_launch_corrected"] / (e["avg_ms"] * 1e-3) / 1e12, 3) if e.get("avg_ms") else None
+                if e.get("calls", 0) >= 12:      # the kernels of an iteration (the prologue's run once)
+                    tot_ms += e["avg_ms"]; tot_b += e["hbm_bytes_per_launch_corrected"]
+        if tot_ms:
+            summ["iteration"] = {"ms_sum_of_launches": round(tot_ms, 5), "hbm_bytes_corrected": int(tot_b), "achieved_TBps": round(tot_b / (tot_ms * 1e-3) / 1e12, 3)}
+        json.dump(summ, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+        print(json.dumps(summ, indent=1))
+
+
+_condense_aux()
