@@ -602,15 +602,18 @@ SPK_DEV constexpr int spk_mfma_row(int kq, int reg) { return kRealIsDouble ? kq 
 SPK_DEV bool mfma_sweep_applies(int nx, int nu, int d) {
     return (nx == 64 && nu == 16 && d == 2) || (nx == 20 && nu == 20 && (d == 2 || d == 3));
 }
+// (the dedicated sweep kernels of spock_skernels.hip add nx = nu = 50, d = 2 -- examples/server_heat/scaling.jl's shape: 13 k-steps
+//  per child, the columns past 50 masked)
 
 // One wave owns a ROW tile m of the level's product and keeps its matrix fragments (KF k-steps: one 8-byte element per lane
 // each) in registers while it runs over the level's node tiles: the fragments are fetched from L2 once per level and wave --
 // their latency (the sweep is a chain of small dependent levels) is paid once, not per node tile.
 // (row_ok: this lane's matrix row exists -- the last row tile of a shape that is not a multiple of 16 is padded with zeros)
+// nk: columns of the matrix (k-steps cover 4 KF >= nk of them: the columns past nk of a shape that is not a multiple of 4 are zero)
 template <int KF, class MPT>
-SPK_DEV void mfma_load_frags(real (&af)[KF], MPT Mx, long ld, int kq, int nk4, int k_base, bool row_ok = true) {
+SPK_DEV void mfma_load_frags(real (&af)[KF], MPT Mx, long ld, int kq, int nk, int k_base, bool row_ok = true) {
 #pragma unroll
-    for (int q = 0; q < KF; ++q) af[q] = (row_ok && q < nk4) ? Mx[(long)(k_base + 4 * q + kq) * ld] : 0.;
+    for (int q = 0; q < KF; ++q) af[q] = (row_ok && 4 * q + kq < nk) ? Mx[(long)(k_base + 4 * q + kq) * ld] : 0.;
 }
 
 // NXC / NUC / DC: compile-time nx / nu / d of the instantiation (64 / 16 / 2 for BASELINE config 5).  Work item = (row tile m,
@@ -622,7 +625,7 @@ SPK_DEV void mfma_load_frags(real (&af)[KF], MPT Mx, long ld, int kq, int nk4, i
 template <int NXC, int NUC, int DC, int SXP = NXC, int SUP = NUC, class P, class MPT>
 SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, int cnt, bool kids_gleaf, int tid, int nthreads,
                             const TeamLds &L, int sxl = NXC) {
-    constexpr int nx = NXC, nu = NUC, d = DC, KQ = NXC / 4;
+    constexpr int nx = NXC, nu = NUC, d = DC, KQ = (NXC + 3) / 4;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int j = lane & 15, kq = lane >> 4;
     constexpr int mq = (nx + 15) / 16, mt = mq + (nu + 15) / 16;
@@ -638,7 +641,7 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
         real af[DC][KQ];
 #pragma unroll
         for (int c = 0; c < d; ++c)
-            mfma_load_frags<KQ>(af[c], (isq ? SW + dm.sw_oW + c * nx * nx : SW + dm.sw_oV + c * nu * nx) + (row_ok ? row0 + j : 0), ld, kq, KQ, 0, row_ok);
+            mfma_load_frags<KQ>(af[c], (isq ? SW + dm.sw_oW + c * nx * nx : SW + dm.sw_oV + c * nu * nx) + (row_ok ? row0 + j : 0), ld, kq, nx, 0, row_ok);
         for (int nt = sp; nt < ntile; nt += nsplit) {
             const int pos = nt * 16 + j;
             const bool valid = pos < cnt;
@@ -653,7 +656,7 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
 #pragma unroll
                 for (int c = 0; c < d; ++c) {
                     const real *qc = kids_gleaf ? L.XL + (long)(posv * d + c) * sxl : L.XQ + (long)(li * d + 1 + c) * SXP;
-                    const real bv = valid ? qc[4 * q + kq] : 0.;
+                    const real bv = (valid && (nx % 4 == 0 || 4 * q + kq < nx)) ? qc[4 * q + kq] : 0.;
                     accc[c] = spk_mfma(af[c][q], bv, accc[c]);
                 }
             }
@@ -676,7 +679,7 @@ SPK_DEV void bwd_level_mfma(const P &p, const Dims &dm, MPT SW, int lvl_first, i
 template <int NXC, int NUC, int DC, int SXP = NXC, int SUP = NUC, class P, class MPT>
 SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_first, int cnt, bool kids_gleaf, int tid, int nthreads,
                             const TeamLds &L, int sxl = NXC) {
-    constexpr int nx = NXC, nu = NUC, d = DC, KQ = NXC / 4, KU = NUC / 4;
+    constexpr int nx = NXC, nu = NUC, d = DC, KQ = (NXC + 3) / 4, KU = (NUC + 3) / 4;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int j = lane & 15, kq = lane >> 4;
     constexpr int mq = (nx + 15) / 16, mu = (nu + 15) / 16;
@@ -693,10 +696,10 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
         const int rj = row_ok ? row0 + j : 0;
         real af[KQ], bf[KU];
         if (isx) {
-            mfma_load_frags<KQ>(af, SW + dm.sw_oABK + c * nx * nx + rj, nx, kq, KQ, 0, row_ok);
-            mfma_load_frags<KU>(bf, Bm + slot_event(c, d) * nx * nu + rj, nx, kq, KU, 0, row_ok);
+            mfma_load_frags<KQ>(af, SW + dm.sw_oABK + c * nx * nx + rj, nx, kq, nx, 0, row_ok);
+            mfma_load_frags<KU>(bf, Bm + slot_event(c, d) * nx * nu + rj, nx, kq, nu, 0, row_ok);
         } else {
-            mfma_load_frags<KQ>(af, SW + dm.sw_oK + rj, nu, kq, KQ, 0, row_ok);
+            mfma_load_frags<KQ>(af, SW + dm.sw_oK + rj, nu, kq, nx, 0, row_ok);
 #pragma unroll
             for (int q = 0; q < KU; ++q) bf[q] = 0.;
         }
@@ -710,7 +713,7 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
             spk_vacc acc = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.}, accb = {0., 0., 0., 0.};
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
-                const real bv = valid ? xi[4 * q + kq] : 0.;
+                const real bv = (valid && (nx % 4 == 0 || 4 * q + kq < nx)) ? xi[4 * q + kq] : 0.;
                 if (q & 1) acc1 = spk_mfma(af[q], bv, acc1);
                 else acc = spk_mfma(af[q], bv, acc);
             }
@@ -718,7 +721,7 @@ SPK_DEV void fwd_level_mfma(const P &p, const Dims &dm, MPT SW, MPT Bm, int lvl_
             if (isx) {
 #pragma unroll
                 for (int q = 0; q < KU; ++q) {
-                    const real bv = valid ? di[4 * q + kq] : 0.;
+                    const real bv = (valid && (nu % 4 == 0 || 4 * q + kq < nu)) ? di[4 * q + kq] : 0.;
                     accb = spk_mfma(bf[q], bv, accb);
                 }
                 acc += accb;

@@ -66,7 +66,7 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     // flat node-local kernels (spock_flat_local.hpp; lane-team shapes): this kernel then runs the S1 sweeps only -- c_i, e_i and the
     // leaves' q come from zbar's x / u entries, where MODE_FLAT_A parked them -- and the flat kernels' workgroups own the partials
     const bool flat = P::TEAMLOCAL && a.flat_local != 0;
-    const int n_groups = flat ? a.flat_chunks : (dm.t0 > 0 ? dm.nsub + 1 : 1);
+    const int n_groups = a.flat_local ? a.flat_chunks : (dm.t0 > 0 ? dm.nsub + 1 : 1);   // (FINALIZE may run under a policy without lane teams)
     double *partials = a.partials + (long)inst * n_groups * kPartialStride;
 
     int stamp_idx = 0;

@@ -241,6 +241,10 @@ FlatGeo flat_geometry(const Dims &dm) {
 bool flat_local_applies(const Dims &dm, int batch) {
     if (const char *e = std::getenv("SPOCK_AMD_FLAT_LOCAL")) { if (e[0] == '0') return false; }
     if (dm.t0 <= 0) return false;                                  // whole tree in one workgroup: nothing to flatten
+    if (!team_local_applies(dm)) return false;
+    // with the dedicated sweep kernels (spock_skernels.hip) the subtree / crown kernels need no lane-team scratch at all: groups whose
+    // sweep vectors alone fill the LDS (nx = nu = 50 with 127-node groups: examples/server_heat/scaling.jl at N = 14, 15) qualify too
+    if (sweep_kernels_apply(dm)) return true;
     return launch_geometry(MODE_SUB_A, dm, batch).team_local != 0 && launch_geometry(MODE_CROWN, dm, batch).team_local != 0;
 }
 

@@ -246,6 +246,7 @@ LaunchGeo launch_geometry(int mode, const Dims &dm, int batch);
 struct FlatGeo { int team, threads, nteams, chunks, ex_doubles; size_t lds_bytes; };
 FlatGeo flat_geometry(const Dims &dm);
 bool flat_local_applies(const Dims &dm, int batch);   // the handle runs its node-local phases as flat kernels
+bool sweep_kernels_apply(const Dims &dm);             // dedicated matrix-core sweep kernels exist for this shape (spock_skernels.hip; false in the host emulation)
 int group_threads(int d, int stages);  // non-leaf nodes of a complete d-ary tree with `stages` stages
 
 // element-major batched regime: split stage (subtrees of at most `max_sub_stages` stages, LDS-bound), launch geometry

@@ -98,7 +98,6 @@ static int launch_variant(int mode, const KArgs &a_in, hipStream_t st) {
 
 
 int launch_flat_local(int mode, const KArgs &a, void *stream);   // flat node-local kernels (spock_fkernels.hip)
-bool sweep_kernels_apply(const Dims &dm);                         // dedicated matrix-core sweep kernels (spock_skernels.hip)
 int launch_sweep(int mode, const KArgs &a, void *stream);
 
 bool have_static_variant(int nx, int nu, int d, int ny) {

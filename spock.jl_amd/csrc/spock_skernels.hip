@@ -56,13 +56,14 @@ __device__ __forceinline__ int sw_nonleaf(int d, int stages) {
 
 // LDS carve (doubles), node vectors with padded strides SX = nx + 4, SU = nu + 4 (LDS banks, see bwd_level_mfma):
 // [XQ nl*SX][ED nl*SU][UL nl*SU (crown, down)][XL ngl*SX when it fits] then the reduction scratch of GpuExec
-constexpr int kSweepPad = 4;
+// (nx = nu = 50: pad 3 -- an odd stride, and 127-node groups with three vectors per node then just fit the 160 KB of LDS)
+constexpr int sweep_pad(int n) { return n == 50 ? 3 : 4; }
 template <int NX, int NU, int D, int MODE>
 __global__ void __launch_bounds__(kSweepThreads) spock_sweep_kernel(const KArgs a, const int xl_up_lds, const int xl_parts) {
     // xl_up_lds: on the way up the group leaves' q is staged in LDS (behind ED: the u vector does not exist yet);
     // xl_parts : on the way down the group leaves' x goes through an LDS staging area behind UL in this many parts (1: all at once;
     //            0: no room at all, the matrix cores' result lanes write it to global memory themselves)
-    constexpr int SX = NX + kSweepPad, SU = NU + kSweepPad;
+    constexpr int SX = NX + sweep_pad(NX), SU = NU + sweep_pad(NU);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const Dims &dm = a.dm;
     const int inst = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -201,7 +202,7 @@ static int launch_sweep_shape(int mode, const KArgs &a_in, hipStream_t st) {
     const int stages = sw == SW_CROWN ? dm.t0 + 1 : dm.sub_stages;
     int nl = 0, ngl = 1;
     { int lvl = 1; for (int t = 0; t < stages - 1; ++t) { nl += lvl; lvl *= D; } ngl = lvl; }
-    constexpr int SX = NX + kSweepPad, SU = NU + kSweepPad;
+    constexpr int SX = NX + sweep_pad(NX), SU = NU + sweep_pad(NU);
     const long tail = 4 + 64;                                                         // GpuExec's reduction scratch (crown)
     const long budget = 160 * 1024 / 8 - 64;
     const long up_base = (long)nl * (SX + SU), down_base = (long)nl * (SX + 2 * SU), xl_full = (long)ngl * SX;
@@ -250,13 +251,15 @@ static int launch_sweep_shape(int mode, const KArgs &a_in, hipStream_t st) {
 bool sweep_kernels_apply(const Dims &dm) {
     static const bool off = std::getenv("SPOCK_AMD_NO_SWEEPK") != nullptr || std::getenv("SPOCK_AMD_NO_MFMA") != nullptr;
     if (off || dm.t0 <= 0) return false;
-    return (dm.nx == 64 && dm.nu == 16 && dm.d == 2) || (dm.nx == 20 && dm.nu == 20 && (dm.d == 2 || dm.d == 3));
+    return (dm.nx == 64 && dm.nu == 16 && dm.d == 2) || (dm.nx == 20 && dm.nu == 20 && (dm.d == 2 || dm.d == 3)) ||
+           (dm.nx == 50 && dm.nu == 50 && dm.d == 2);
 }
 
 int launch_sweep(int mode, const KArgs &a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const Dims &dm = a.dm;
     if (dm.nx == 64) return launch_sweep_shape<64, 16, 2>(mode, a, st);
+    if (dm.nx == 50) return launch_sweep_shape<50, 50, 2>(mode, a, st);
     if (dm.d == 2) return launch_sweep_shape<20, 20, 2>(mode, a, st);
     return launch_sweep_shape<20, 20, 3>(mode, a, st);
 }

@@ -116,6 +116,8 @@ static int launch_variant(int mode, const KArgs &a_in) {
 }
 
 
+bool sweep_kernels_apply(const Dims &) { return false; }   // the matrix-core sweep kernels are gfx950 code: the emulation runs group_body's sweeps
+
 // flat node-local kernels (spock_flat_local.hpp)
 template <class P, int MODE>
 static void run_flat_blocks(const KArgs &a, int gx, int thr) {

@@ -222,3 +222,38 @@ def test_cfg3_sp_first_iterations_full_size(S, O):
     assert np.array_equal(h["backtrack"], ro["hist_backtrack"])
     assert relerr(m.solver_state.z, o.z) <= 1e-6 and relerr(m.solver_state.v, o.v) <= 1e-6
     m.close()
+
+
+def test_scaling_jl_shape_nx50(S, O):
+    """examples/server_heat/scaling.jl's shape (nx = nu = 50, d = 2) on the flat node-local kernels + the matrix-core sweep kernels
+    instantiated for it (13 k-steps per child, the columns past 50 masked; spock_skernels.hip): operators and 20 CP iterations
+    against the oracle at N = 9, the first SP iterations of the solve scaling.jl times; and N = 14 -- whose 127-node groups fill the
+    LDS with their sweep vectors alone and used to fall back to one thread per node -- through a size-independent property:
+    the solved iterate satisfies the dynamics x_j = A_w x_i + B_w u_i (test/model_dynamics/implicit_L.jl:59-66) on every edge."""
+    specs = S.get_server_heat_specs(9, 50, 2)
+    flat, sizes = _cp_block(S, O, specs, None, 20, 77)
+    assert sizes.split_stage > 0
+    x0 = np.full(50, 0.1)
+    ms = S.build_model(*specs, S.SolverOptions(S.SP, None), max_iter=12)
+    S.solve_model(ms, x0, tol=1e-12, verbose=S.LOG)
+    o = O.Oracle(flat, O.SP)
+    ro = o.solve(x0, tol=1e-12, verbose=O.LOG, max_iter=12, history=20)
+    h = ms.history()
+    assert np.max(np.abs(h["xi"] - ro["hist_xi"]) / ro["hist_xi"]) <= 1e-8 and np.array_equal(h["backtrack"], ro["hist_backtrack"])
+    ms.close()
+    specs = S.get_server_heat_specs(14, 50, 2)
+    f14 = S.flatten_problem(*specs)
+    m = S.build_model(*specs, max_iter=30)
+    assert [n for n, _, _ in m.profile_sequence(1)] == ["sub_a", "crown", "sub_b", "flat_ba"]      # the flat path, not the fallback
+    m.reset()
+    r = S.solve_model(m, x0, tol=0.0)
+    z = m.solver_state.z
+    sl = f14.z_slices()
+    X = z[sl["x"]].reshape(f14.n, 50); U = z[sl["u"]].reshape(f14.nn, 50)
+    A, B = specs[2].A, specs[2].B
+    worst = 0.0
+    for j in list(range(1, 64)) + list(range(f14.n - 64, f14.n)):
+        i, w = (j - 1) // 2, (j + 1) % 2
+        worst = max(worst, float(np.max(np.abs(X[j] - (A[w] @ X[i] + B[w] @ U[i])))))
+    assert r["iterations"] == 30 and np.isfinite(z).all() and np.max(np.abs(X[0] - x0)) == 0.0 and worst <= 1e-12
+    m.close()
