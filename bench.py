@@ -353,7 +353,11 @@ def main(argv=None):
     # ---- BASELINE config 4: closed-loop MPC simulations sharded over the ranks (the metric's problems/sec leg)
     if not args.no_mpc:
         mspecs = S.get_server_heat_specs(args.mpc_N, args.mpc_nx, 2)
+        mflat = S.flatten_problem(*mspecs)
         steps = args.mpc_steps
+        # SURVEY 8d's bytes_SP per instance-iteration of this problem: 2 bytes_T + 26 W (nz + nv)
+        m_bytes_T = 8 * (4 * mflat.nz + 3 * mflat.nv + 2 * (mflat.n * mflat.nx + mflat.nn * mflat.nu))
+        m_bytes_SP = 2 * m_bytes_T + 26 * 8 * (mflat.nz + mflat.nv)
         legs = {}
         for name, total in (("weak", args.mpc_per_gpu * world), ("strong", args.mpc_total)):
             lo, hi = sdist.shard_range(total, world, rank)
@@ -374,10 +378,14 @@ def main(argv=None):
                           "steps_per_simulation": steps, "ms": round(dt * 1e3, 2),
                           "problems_per_s": round(total / dt, 2), "solves_per_s": round(total * steps / dt, 1),
                           "sp_iterations_total": int(recs[:, args.mpc_nx].sum()), "all_converged": bool((recs[:, args.mpc_nx + 1] == 0).all()),
-                          "max_final_state": float(recs[:, args.mpc_nx + 2].max())}
+                          "max_final_state": float(recs[:, args.mpc_nx + 2].max()),
+                          # whole-leg rate on SURVEY 8d's bytes_SP (every SP iteration of every simulation priced at bytes_SP) against the HBM peak of the GPUs in use
+                          "bytes_SP_per_instance_iteration": m_bytes_SP,
+                          "hbm_frac_on_bytes_SP": round(int(recs[:, args.mpc_nx].sum()) * m_bytes_SP / dt / 1e9 / (HBM_PEAK_GBS * n_gpus), 4)}
         out["mpc_cfg4"] = dict(legs, workload=f"mpc_simulation.jl: server_heat nx=nu={args.mpc_nx}, d=2, N={args.mpc_N}, SP, tol 1e-3, "
                                               f"{steps} warm-started steps per simulation; one all_gather of (nu+5) doubles per simulation",
-                               unit="closed-loop simulations/s")
+                               unit="closed-loop simulations/s",
+                               driver="steps chained on the device (SP_CTL_M): a finished instance applies u, advances x0 and starts its next warm-started solve without the host")
 
     if rank == 0 and world == 1 and on_gpu:
         from oracle import oracle as O

@@ -29,8 +29,21 @@ static int launch_flat(int mode, const KArgs &a_in, hipStream_t st) {
     const FlatGeo g = flat_geometry(a_in.dm);
     KArgs a = a_in;
     a.team = g.team; a.ex_doubles = g.ex_doubles; a.flat_chunks = g.chunks;
-    if (g.lds_bytes > 64 * 1024) return (int)hipErrorInvalidConfiguration;
+    if (g.lds_bytes > 160 * 1024) return (int)hipErrorInvalidConfiguration;
     const dim3 grid(g.chunks, a.batch), block(g.threads);
+    const int mi = mode - MODE_FLAT_A;
+    if (g.lds_bytes > 64 * 1024) {   // wide shapes (nx, nu ~ 64: the staged U_t, Rt^-1_t alone are 50 KB): raise the dynamic-LDS limit once per kernel and device
+        static bool raised[16][4] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+        if (!raised[dev][mi]) {
+            const void *fn = mode == MODE_FLAT_A ? (const void *)spock_flat_kernel<P, MODE_FLAT_A> : mode == MODE_FLAT_B ? (const void *)spock_flat_kernel<P, MODE_FLAT_B>
+                           : mode == MODE_FLAT_B_SP ? (const void *)spock_flat_kernel<P, MODE_FLAT_B_SP> : (const void *)spock_flat_kernel<P, MODE_FLAT_BA>;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised[dev][mi] = true;
+        }
+    }
     switch (mode) {
         case MODE_FLAT_A: hipLaunchKernelGGL((spock_flat_kernel<P, MODE_FLAT_A>), grid, block, g.lds_bytes, st, a); break;
         case MODE_FLAT_B: hipLaunchKernelGGL((spock_flat_kernel<P, MODE_FLAT_B>), grid, block, g.lds_bytes, st, a); break;

@@ -670,3 +670,22 @@ def test_mpc_steps_chained_on_the_device(S, O, monkeypatch):
         assert len({n for rb in out["host"][2] for n, _ in rb}) > 2            # instances stop at different iterations
         for k in (0, 1, 3):
             assert np.array_equal(out["chain"][k], out["host"][k])
+
+
+@pytest.mark.parametrize("nx,nu,d,N", [(64, 56, 2, 6), (33, 17, 3, 4), (48, 48, 4, 4)])
+def test_flat_node_local_kernels_awkward_shapes(S, O, nx, nu, d, N):
+    """Flat node-local kernels (spock_flat_local.hpp) at shapes without a matrix-core sweep kernel: lane teams of 64 with nu close to
+    nx (the staged U_t / Rt^-1_t pass the default 64 KB of dynamic LDS: a fuzz run found the launch refused there), odd sizes, d = 3, 4.
+    Operator T and 30 CP iterations against the oracle, two instances."""
+    specs = S.get_random_linear_specs(N, nx, nu, d=d, seed=nx * 100 + nu)
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, L_norm="auto", max_iter=30, batch=2, split_stage=2)
+    assert [n for n, _, _ in m.profile_sequence(1)][-1] == "flat_ba"
+    m.reset()
+    x0 = 0.1 * np.cos(np.arange(nx)); X0 = np.stack([x0, 1.3 * x0])
+    rs = S.solve_model(m, X0, tol=0.0)
+    for b in range(2):
+        o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm
+        o.solve(X0[b], tol=0.0, max_iter=30)
+        assert rs[b]["iterations"] == 30 and relerr(m.solver_state.z[b], o.z) <= 1e-10 and relerr(m.solver_state.v[b], o.v) <= 1e-10
+    m.close()

@@ -27,8 +27,13 @@ def random_case():
     nu = int(rng.integers(1, nx + 1))
     if rng.random() < 0.25 and nx in (5,):
         nu = int(rng.choice([2, 5]))
+    if os.environ.get("SPOCK_FUZZ_MFMA"):    # the shapes with matrix-core sweep kernels (spock_skernels.hip) + flat node-local kernels
+        nx, nu, d = [(64, 16, 2), (20, 20, 2), (20, 20, 3), (50, 50, 2)][int(rng.integers(0, 4))]
+        N = int(rng.integers(4, 9)) if d == 2 else int(rng.integers(3, 6))
     tree, cost, dyn, rms, con = S.get_random_linear_specs(N, nx, nu, d=d, seed=int(rng.integers(1 << 30))) if _has_d() else S.get_random_linear_specs(N, nx, nu)
     kind = rng.choice(["diag", "dense_shared", "per_node"], p=[0.6, 0.2, 0.2])
+    if os.environ.get("SPOCK_FUZZ_MFMA"):
+        kind = "diag"                        # (the lane-team phases exist for shared diagonal costs)
 
     def spd(n):
         a = rng.standard_normal((n, n)); return 0.05 * (a @ a.T) / n + np.eye(n) * 0.1
