@@ -370,7 +370,7 @@ SpArgs make_sp_args(spock_handle_s *h, int op) {
     std::memset(&a, 0, sizeof(a));
     const Dims &dm = h->bp.dm;
     a.dm = dm; a.mats = h->d_mats; a.ctl = h->d_ctl; a.sp = h->s_ctl;
-    a.Z = h->s_vec[SV_Z]; a.ZB = h->s_vec[SV_ZB]; a.ZOLD = h->s_vec[SV_ZOLD]; a.R = h->s_vec[SV_R]; a.ROLD = h->s_vec[SV_ROLD];
+    a.Z = h->s_vec[SV_Z]; a.ZB = h->s_vec[SV_ZB]; a.ZOLD = h->s_vec[SV_ZOLD]; a.R = h->s_vec[SV_R]; a.ROLD = h->s_vec[SV_R];   // r and r_old share a buffer (spock_sp.hpp: FLAT1)
     a.DP = h->s_vec[SV_DP]; a.W = h->s_vec[SV_W]; a.WB = h->s_vec[SV_WB]; a.RW = h->s_vec[SV_RW]; a.D = h->s_vec[SV_D];
     a.MP = h->s_MP; a.Q = h->s_Q; a.partF = h->s_partF; a.partL = h->s_partL;
     a.hist = h->d_hist; a.hist_cap = h->hist_cap;
@@ -451,7 +451,7 @@ int sp_init_state(spock_handle_s *h) {
     const size_t B = (size_t)h->batch, nr = (size_t)dm.nz + dm.nv;
     for (int k = 0; k < 10; ++k) { if (!h->s_vec[k]) continue; int e = rt::dzero(h->s_vec[k], B * nr * sizeof(real), h->stream); if (e) return e; }
     std::vector<double> ones(B * nr, 1.0);
-    int e = up(h, h->s_vec[SV_ROLD], ones.data(), B * nr);   // rz_old = rv_old = 1 (models/spock.jl:159-201); z_old itself is not stored (spock_sp.hpp: FLAT5)
+    int e = up(h, h->s_vec[SV_R], ones.data(), B * nr);   // rz_old = rv_old = 1 (models/spock.jl:159-201) in the buffer r shares with r_old; z_old itself is not stored (spock_sp.hpp: FLAT1, FLAT5)
     if (!e) e = rt::sync(h->stream);
     if (!e) e = rt::dzero(h->s_MP, B * 3 * nr * sizeof(real), h->stream);
     if (!e) e = rt::dzero(h->s_Q, B * 3 * nr * sizeof(real), h->stream);
@@ -777,7 +777,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     } else {
         const size_t nr = (size_t)dm.nz + dm.nv;
         for (int k = 0; k < 10; ++k) {
-            if (k == SV_ZOLD || (k == SV_RW && !std::getenv("SPOCK_AMD_SP_LOP"))) continue;   // not stored (FLAT5) / only the separate-LOP sequence forms rt = w - wbar
+            if (k == SV_ZOLD || k == SV_ROLD || (k == SV_RW && !std::getenv("SPOCK_AMD_SP_LOP"))) continue;   // not stored (FLAT1, FLAT5) / only the separate-LOP sequence forms rt = w - wbar
             if ((e = dev_alloc(h, &h->s_vec[k], B * nr))) return bail(e, "hipMalloc(SP state)");
         }
         if ((e = dev_alloc(h, &h->s_MP, B * 3 * nr)) || (e = dev_alloc(h, &h->s_Q, B * 3 * nr)) ||

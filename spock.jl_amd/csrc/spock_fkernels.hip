@@ -10,8 +10,16 @@
 namespace spock {
 
 // flat node-local kernels of the lane-team shapes (spock_flat_local.hpp): blockIdx.x = chunk of 16 consecutive non-leaf nodes
+#ifndef FLAT_WAVES          // experiment builds: waves per SIMD the phase-B kernels are compiled for (register budget 512 / that)
+#define FLAT_WAVES 0
+#endif
+#if FLAT_WAVES
+#define SPK_FLAT_ATTR __attribute__((amdgpu_waves_per_eu(FLAT_WAVES, FLAT_WAVES)))
+#else
+#define SPK_FLAT_ATTR
+#endif
 template <class P, int MODE>
-__global__ void __launch_bounds__(256) spock_flat_kernel(const KArgs a) {
+__global__ void __launch_bounds__(256) SPK_FLAT_ATTR spock_flat_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpuExec<P> x;
     x.ex = reinterpret_cast<real *>(smem);

@@ -43,11 +43,13 @@ SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, dou
     switch (a.op) {
         case SP_FLAT1: {   // head already points at the slot of the new column (set by CTL_D / solve start)
             const real z = a.Z[o], r = z - a.ZB[o];
-            const real dr = r - a.ROLD[o];
+            // r_old of update_sy! (sp.jl:232-255) and r live in ONE buffer: from here to the next FLAT1 both are this iteration's r
+            // (a.ROLD aliases a.R) -- the old value is read, the new one written in place: one vector less written per iteration
+            const real dr = r - a.R[o];
             a.R[o] = r;
             p1[e] = a.DP[o] - dr;                 // MP[:,1] = delta_p - delta_r   (anderson.jl:25-32)
             q1[e] = dr;                           // Q[:,1]  = MR[:,1] = delta_r   (anderson.jl:63-65)
-            a.ROLD[o] = r;                        // update_sy! (sp.jl:232-255); z_old <- z needs no copy: see FLAT5
+            // (z_old <- z of update_sy! needs no copy either: see FLAT5)
             const real b = q2[e], cc = q3[e];
             sums[0] += dr * dr; sums[1] += b * dr; sums[2] += cc * dr; sums[3] += b * b; sums[4] += cc * cc; sums[5] += b * cc;
             sums[6] += dr * r; sums[7] += b * r; sums[8] += cc * r;      // MR'r: right-hand side of the corrected variant's normal equations
