@@ -106,7 +106,8 @@ typedef struct {
                            * sp.jl:439, coefficients written into row 1 of R anderson.jl:86); 1: the corrected variant -- least-squares
                            * Anderson and a line search that shortens the step (no reference counterpart; measures what the defects cost) */
     int32_t sp_max_backtrack; /* sp_variant 1: candidates tried after the first, 0 -> run_sp!'s MAX_BACKTRACK_COUNT = 8 (sp.jl:371) */
-    int32_t reserved_;
+    int32_t per_instance_dynamics; /* 1: every instance of the batch gets a matrix pool of its own, so that spock_update_dynamics_batch can
+                           * give each its own A_w, B_w (Monte-Carlo draws of the dynamics; instance-major layout only).  0: one pool. */
 } spock_options_t;
 
 typedef struct {
@@ -188,6 +189,11 @@ int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_
  * kept.  The reference rebuilds the whole model (build_model) when the dynamics change; this replaces that for e.g. a model
  * re-linearised between the steps of a closed loop.  SPOCK_ERR_BUILD when Rtilde is not positive definite. */
 int spock_update_dynamics(spock_handle_t h, const double *A, const double *B);
+/* The same for a BATCH OF DRAWS: instance b of the handle gets A[b] ([d][nx*nx]) and B[b] ([d][nx*nu]); the device builds all of them
+ * side by side (one workgroup each).  Needs spock_options_t.per_instance_dynamics.  status: optional [batch], SPOCK_OK / SPOCK_ERR_BUILD per
+ * instance; an instance whose build fails keeps its previous dynamics, the call then returns SPOCK_ERR_BUILD.  The reference builds one model
+ * per draw (build_model, src/model.jl:273-297). */
+int spock_update_dynamics_batch(spock_handle_t h, const double *A, const double *B, int32_t *status);
 
 /* L_norm in use (step sizes default to 0.99/sqrt(L_norm), cp.jl:198-201) and the closed-form ||L||^2 of this problem */
 int spock_L_norm(spock_handle_t h, double *in_use, double *closed_form);

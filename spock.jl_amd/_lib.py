@@ -33,7 +33,7 @@ class Problem(C.Structure):
 class Options(C.Structure):
     _fields_ = [("algorithm", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("split_stage", C.c_int32),
                 ("L_norm", C.c_double), ("max_iter", C.c_int32), ("graph_iters", C.c_int32), ("batch_layout", C.c_int32),
-                ("sp_variant", C.c_int32), ("sp_max_backtrack", C.c_int32), ("reserved_", C.c_int32)]
+                ("sp_variant", C.c_int32), ("sp_max_backtrack", C.c_int32), ("per_instance_dynamics", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -72,6 +72,7 @@ SYMBOLS = {
     "spock_get_timing": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_I)]),
     "spock_profile_kernels": (C.c_int, [_P, _I, _P, _P]),
     "spock_update_dynamics": (C.c_int, [_P, _P, _P]),
+    "spock_update_dynamics_batch": (C.c_int, [_P, _P, _P, _P]),
     "spock_profile_sequence": (C.c_int, [_P, _I, _P, _P, _P, _I, _P]),
     "spock_debug_stamps": (C.c_int, [_P, _P]),
     "spock_last_error": (C.c_char_p, []),

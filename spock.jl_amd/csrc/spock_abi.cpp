@@ -50,6 +50,7 @@ struct spock_handle_s {
     // FLAT_A + SUB_A + CROWN + SUB_B + FLAT_B
     bool flat_local = false;
     int flat_chunks = 0;
+    long mats_stride = 0;   // > 0: every instance has its own matrix pool of this many elements (spock_options_t.per_instance_dynamics)
     real *d_dbuf = nullptr, *d_qroot = nullptr, *d_cbuf = nullptr, *d_x0 = nullptr, *d_xlbuf = nullptr;
     double *d_partials = nullptr, *d_hist = nullptr;   // residual maxima / sums and the residual log stay double
     // element-major batched regime (spock_igroup.hpp): the iterate as [element][bp]; d_z / d_v then serve as instance-major
@@ -137,6 +138,7 @@ KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
     std::memset(&a, 0, sizeof(a));
     a.dm = h->bp.dm;
     a.mats = h->d_mats;
+    a.mats_stride = op ? 0 : h->mats_stride;   // (the operator entry points work on instance 0's pool)
     if (!op) {
         a.z_in = h->d_z[parity % 3]; a.v_in = h->d_v[parity % 2];
         a.z_out = h->d_z[(parity + 1) % 3]; a.v_out = h->d_v[(parity + 1) % 2];
@@ -369,7 +371,7 @@ SpArgs make_sp_args(spock_handle_s *h, int op) {
     SpArgs a;
     std::memset(&a, 0, sizeof(a));
     const Dims &dm = h->bp.dm;
-    a.dm = dm; a.mats = h->d_mats; a.ctl = h->d_ctl; a.sp = h->s_ctl;
+    a.dm = dm; a.mats = h->d_mats; a.mats_stride = h->mats_stride; a.ctl = h->d_ctl; a.sp = h->s_ctl;
     a.Z = h->s_vec[SV_Z]; a.ZB = h->s_vec[SV_ZB]; a.ZOLD = h->s_vec[SV_ZOLD]; a.R = h->s_vec[SV_R]; a.ROLD = h->s_vec[SV_R];   // r and r_old share a buffer (spock_sp.hpp: FLAT1)
     a.DP = h->s_vec[SV_DP]; a.W = h->s_vec[SV_W]; a.WB = h->s_vec[SV_WB]; a.RW = h->s_vec[SV_RW]; a.D = h->s_vec[SV_D];
     a.MP = h->s_MP; a.Q = h->s_Q; a.partF = h->s_partF; a.partL = h->s_partL;
@@ -708,7 +710,9 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     int layout = o ? o->batch_layout : 0;
     if (const char *e = std::getenv("SPOCK_AMD_ILV")) layout = (e[0] == '1') ? 2 : 1;
     if (layout < 0 || layout > 2) { delete h; return fail(SPOCK_ERR_BAD_ARG, "batch_layout must be 0 (choose), 1 (instance-major) or 2 (element-major)"); }
-    const bool ilv_possible = alg == SPOCK_ALG_CP && N >= 3 && have_static_variant(nx, nu, d, ny) && hp.nQ == 1 && hp.nR == 1 && hp.nQN == 1 && hp.n_rms == 1;
+    const bool per_inst = o && o->per_instance_dynamics != 0;
+    if (per_inst && layout == 2) { delete h; return fail(SPOCK_ERR_UNSUPPORTED, "per-instance dynamics need the instance-major layout (in the element-major kernels a matrix element is one scalar for 64 instances)"); }
+    const bool ilv_possible = !per_inst && alg == SPOCK_ALG_CP && N >= 3 && have_static_variant(nx, nu, d, ny) && hp.nQ == 1 && hp.nR == 1 && hp.nQN == 1 && hp.n_rms == 1;
     if (layout == 2 && !ilv_possible) { delete h; return fail(SPOCK_ERR_UNSUPPORTED, "the element-major batch layout exists for CP, the compile-time shapes and shared cost matrices"); }
     bool want_ilv = ilv_possible && (layout == 2 || (layout == 0 && h->batch >= 320));
     if (!ilv_possible && layout != 1 && h->batch >= 320) h->layout_reason = 1;
@@ -745,8 +749,12 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     if ((e = rt::stream_create(&h->stream))) return bail(e, "hipStreamCreate");
     if ((e = rt::event_create(&h->ev0)) || (e = rt::event_create(&h->ev1))) return bail(e, "hipEventCreate");
     const size_t B = (size_t)h->batch;
-    if ((e = dev_alloc(h, &h->d_mats, h->bp.mats.size()))) return bail(e, "hipMalloc(matrix pool)");
-    if ((e = up(h, h->d_mats, h->bp.mats.data(), h->bp.mats.size()))) return bail(e, "upload");
+    // one matrix pool for the batch, or -- per_instance_dynamics -- one per instance (all equal until spock_update_dynamics_batch)
+    const size_t pool_n = h->bp.mats.size();
+    h->mats_stride = (o && o->per_instance_dynamics != 0) ? (long)pool_n : 0;
+    if ((e = dev_alloc(h, &h->d_mats, pool_n * (h->mats_stride ? B : 1)))) return bail(e, "hipMalloc(matrix pool)");
+    for (size_t b = 0; b < (h->mats_stride ? B : 1); ++b)
+        if ((e = up(h, h->d_mats + b * pool_n, h->bp.mats.data(), pool_n))) return bail(e, "upload");
     const size_t W = h->ilv ? (size_t)h->bpad : B;   // columns of the per-instance work arrays
     if (alg == SPOCK_ALG_CP && h->ilv) {
         if ((e = dev_alloc(h, &h->d_z[0], B * dm.nz)) || (e = dev_alloc(h, &h->d_v[0], B * dm.nv))) return bail(e, "hipMalloc(staging)");
@@ -898,7 +906,7 @@ int spock_mpc_simulate(spock_handle_t h, const double *x0, int32_t steps, const 
             if (results) for (size_t b = 0; b < B; ++b) results[b * steps + t] = step_res[b];
             MpcArgs a;
             std::memset(&a, 0, sizeof(a));
-            a.dm = dm; a.mats = h->d_mats; a.x0 = h->d_x0; a.w_seq = d_w; a.x_traj = d_xt; a.u_traj = d_ut;
+            a.dm = dm; a.mats = h->d_mats; a.mats_stride = h->mats_stride; a.x0 = h->d_x0; a.w_seq = d_w; a.x_traj = d_xt; a.u_traj = d_ut;
             a.t = t; a.steps = steps; a.batch = h->batch;
             a.stride_e = 1;
             if (h->alg == SPOCK_ALG_SP) { a.z = h->s_vec[0]; a.stride_z = (long)dm.nz + dm.nv; }
@@ -1159,51 +1167,77 @@ int spock_get_build_product(spock_handle_t h, int32_t which, double *out, int32_
     return SPOCK_OK;
 }
 
-// The dynamics-dependent part of the build step on the device (spock_build.hpp): ricatti_offline (implicit_l.jl:46-97) and the
-// composite sweep matrices for new A_w, B_w of the same shape, written into the handle's matrix pool.
-int spock_update_dynamics(spock_handle_t h, const double *A, const double *B) {
-    if (!h || !A || !B) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+// The dynamics-dependent part of the build step on the device (spock_build.hpp): ricatti_offline (implicit_l.jl:46-97) and the composite
+// sweep matrices for new A_w, B_w of the same shape, written into the handle's matrix pool(s).  n_draws = 1: one (A, B) for every
+// instance; n_draws = batch (per_instance_dynamics handles): instance b gets A[b], B[b] -- a batch of Monte-Carlo draws of the dynamics
+// builds side by side, one workgroup per instance.  The kernel rewrites the dynamics-dependent regions of the LIVE pool in place (A, B,
+// K, Rtilde^-1, P, ABK, U / W / V, the sweep blocks); a failed build (Rtilde not positive definite) must leave an instance as it was:
+// the pools are snapshot first, the pools of failed instances restored, and the host-side copies touched only on full success.
+static int update_dynamics_impl(spock_handle_t h, const double *A, const double *B, int n_draws, int32_t *status_out) {
     DeviceGuard guard(h->device);
     const Dims &dm = h->bp.dm;
     const size_t na = (size_t)dm.d * dm.nx * dm.nx, nb = (size_t)dm.d * dm.nx * dm.nu;
-    for (size_t k = 0; k < na; ++k) if (!std::isfinite(A[k])) return fail(SPOCK_ERR_BAD_ARG, "A must be finite");
-    for (size_t k = 0; k < nb; ++k) if (!std::isfinite(B[k])) return fail(SPOCK_ERR_BAD_ARG, "B must be finite");
-    // The kernel rewrites the dynamics-dependent regions of the LIVE pool in place (A, B, K, Rtilde^-1, P, ABK, U / W / V, the sweep
-    // blocks).  A failed build (Rtilde not positive definite) must leave the handle as it was: snapshot the pool (it is small --
-    // stage-shared matrices), restore it on failure, and touch the host-side copies only on success.
+    for (size_t k = 0; k < na * n_draws; ++k) if (!std::isfinite(A[k])) return fail(SPOCK_ERR_BAD_ARG, "A must be finite");
+    for (size_t k = 0; k < nb * n_draws; ++k) if (!std::isfinite(B[k])) return fail(SPOCK_ERR_BAD_ARG, "B must be finite");
+    const size_t n_pools = h->mats_stride ? (size_t)h->batch : 1, pool_n = h->bp.mats.size();
+    // one draw for a handle with per-instance pools: every instance gets it
+    std::vector<double> Arep, Brep;
+    if (n_pools > 1 && n_draws == 1) {
+        Arep.resize(na * n_pools); Brep.resize(nb * n_pools);
+        for (size_t b = 0; b < n_pools; ++b) { std::memcpy(&Arep[b * na], A, na * sizeof(double)); std::memcpy(&Brep[b * nb], B, nb * sizeof(double)); }
+        A = Arep.data(); B = Brep.data();
+    }
     void *dA = nullptr, *dB = nullptr, *dws = nullptr, *dst = nullptr, *dsnap = nullptr;
-    const size_t pool_bytes = h->bp.mats.size() * sizeof(real);
-    int e = rt::dmalloc(&dA, na * sizeof(double));
-    if (!e) e = rt::dmalloc(&dB, nb * sizeof(double));
-    if (!e) e = rt::dmalloc(&dws, (size_t)build_ws_doubles(dm) * sizeof(double));
-    if (!e) e = rt::dmalloc(&dst, sizeof(int));
+    const size_t pool_bytes = pool_n * n_pools * sizeof(real);
+    int e = rt::dmalloc(&dA, na * n_pools * sizeof(double));
+    if (!e) e = rt::dmalloc(&dB, nb * n_pools * sizeof(double));
+    if (!e) e = rt::dmalloc(&dws, (size_t)build_ws_doubles(dm) * n_pools * sizeof(double));
+    if (!e) e = rt::dmalloc(&dst, n_pools * sizeof(int));
     if (!e) e = rt::dmalloc(&dsnap, pool_bytes);
-    int status = 0;
+    std::vector<int> status(n_pools, 0);
     if (!e) e = rt::d2d(dsnap, h->d_mats, pool_bytes, h->stream);
-    if (!e) e = rt::h2d(dA, A, na * sizeof(double), h->stream);
-    if (!e) e = rt::h2d(dB, B, nb * sizeof(double), h->stream);
+    if (!e) e = rt::h2d(dA, A, na * n_pools * sizeof(double), h->stream);
+    if (!e) e = rt::h2d(dB, B, nb * n_pools * sizeof(double), h->stream);
     bool launched = false;
     if (!e) {
         BuildArgs a;
+        std::memset(&a, 0, sizeof(a));
         a.dm = dm; a.mats = h->d_mats; a.A = (const double *)dA; a.B = (const double *)dB; a.ws = (double *)dws; a.status = (int *)dst;
+        a.mats_stride = (long)pool_n; a.n_inst = (int)n_pools;
         e = launch_build_riccati(a, h->stream);
         launched = true;
     }
-    if (!e) e = rt::d2h(&status, dst, sizeof(int), h->stream);
+    if (!e) e = rt::d2h(status.data(), dst, n_pools * sizeof(int), h->stream);
     if (!e) e = rt::sync(h->stream);
-    if (launched && (e || status != 0)) {   // roll back: the pool is again the one of the last successful build
-        int e2 = rt::d2d(h->d_mats, dsnap, pool_bytes, h->stream);
+    bool any_failed = false;
+    for (size_t b = 0; b < n_pools; ++b) any_failed = any_failed || status[b] != 0;
+    if (launched && (e || any_failed)) {   // roll back: a failed instance's pool is again the one of its last successful build
+        int e2 = 0;
+        for (size_t b = 0; b < n_pools && !e2; ++b)
+            if (e || status[b] != 0) e2 = rt::d2d(h->d_mats + b * pool_n, (const real *)dsnap + b * pool_n, pool_n * sizeof(real), h->stream);
         if (!e2) e2 = rt::sync(h->stream);
         if (e2 && !e) e = e2;
     }
     for (void *q : {dA, dB, dws, dst, dsnap}) if (q) rt::dfree(q);
+    if (status_out) for (size_t b = 0; b < n_pools; ++b) status_out[b] = status[b] ? SPOCK_ERR_BUILD : SPOCK_OK;
     if (e) return fail(SPOCK_ERR_HIP, std::string("spock_update_dynamics: ") + rt::err(e));
-    if (status != 0) return fail(SPOCK_ERR_BUILD, "Rtilde is not positive definite (the model keeps its previous dynamics)");
-    h->hp.A.assign(A, A + na); h->hp.B.assign(B, B + nb);
-    h->dyn_on_device = true;
     if (h->graph) { rt::graph_destroy(h->graph); h->graph = nullptr; }        // (the captured launches carry no pool contents, but stay on the safe side)
     if (h->graph_log) { rt::graph_destroy(h->graph_log); h->graph_log = nullptr; }
+    if (h->graph_mpc) { rt::graph_destroy(h->graph_mpc); h->graph_mpc = nullptr; }
+    if (any_failed) return fail(SPOCK_ERR_BUILD, n_pools > 1 ? "Rtilde is not positive definite for at least one instance (those instances keep their previous dynamics)"
+                                                               : "Rtilde is not positive definite (the model keeps its previous dynamics)");
+    h->hp.A.assign(A, A + na); h->hp.B.assign(B, B + nb);   // (instance 0's, what spock_get_build_product reports on)
+    h->dyn_on_device = true;
     return SPOCK_OK;
+}
+int spock_update_dynamics(spock_handle_t h, const double *A, const double *B) {
+    if (!h || !A || !B) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    return update_dynamics_impl(h, A, B, 1, nullptr);
+}
+int spock_update_dynamics_batch(spock_handle_t h, const double *A, const double *B, int32_t *status) {
+    if (!h || !A || !B) return fail(SPOCK_ERR_BAD_ARG, "NULL argument");
+    if (!h->mats_stride && h->batch > 1) return fail(SPOCK_ERR_BAD_ARG, "the handle was created without per_instance_dynamics: its instances share one matrix pool");
+    return update_dynamics_impl(h, A, B, h->batch, status);
 }
 
 static int profile_impl(spock_handle_t h, int32_t reps, double *avg_ms, int32_t *launches, int32_t *seq_modes, int32_t *seq_levels,

@@ -360,7 +360,8 @@ SPK_DEV void flat_body(X &x, const KArgs &a, int inst, int g) {
     const unsigned flags = a.flags;
     Ctl &ctl = a.ctl[inst];
     if (!(flags & F_NO_CTL) && ctl.done) return;
-    const MatPtr M = (MatPtr)a.mats;
+    const real *mats = a.mats + (long)inst * a.mats_stride;   // (per-instance pools: spock_update_dynamics_batch)
+    const MatPtr M = (MatPtr)mats;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), nthr = x.nthreads();
     const int T = a.team, nteams = nthr / T, m = ny + 2 * d;
     const int stride = flat_scratch_doubles(nu, m, d, T);
@@ -386,7 +387,7 @@ SPK_DEV void flat_body(X &x, const KArgs &a, int inst, int g) {
     const int stage0 = flat_team_node(dm, d, node0).stage;
     auto stage_mats = [&]() SPK_LAMBDA_INLINE {          // issued first thing: one coalesced copy, overlapping the node loads of part 1
         x.each([&](int tid, TState<P> &) {
-            const real *sU = a.mats + dm.mU + (long)stage0 * nx * nu, *sR = a.mats + dm.mRinv + (long)stage0 * nu * nu, *sL = a.mats + dm.mLs;
+            const real *sU = mats + dm.mU + (long)stage0 * nx * nu, *sR = mats + dm.mRinv + (long)stage0 * nu * nu, *sL = mats + dm.mLs;
             for (int k = tid; k < nx * nu; k += nthr) lmat[k] = sU[k];
             for (int k = tid; k < nu * nu; k += nthr) lmat[nx * nu + k] = sR[k];
             if (dm.nRm <= 1) for (int k = tid; k < m * m; k += nthr) lmat[nx * nu + nu * nu + k] = sL[k];

@@ -119,7 +119,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     stamp();   // 1: control done
 
 
-    const MatPtr M = (MatPtr)a.mats;
+    const real *mats = a.mats + (long)inst * a.mats_stride;   // (per-instance pools: spock_update_dynamics_batch)
+    const MatPtr M = (MatPtr)mats;
     const real *z = a.z_in + (long)inst * a.stride_z;
     const real *v = a.v_in + (long)inst * a.stride_v;
     real *zo = a.z_out + (long)inst * a.stride_z;
@@ -145,8 +146,8 @@ SPK_DEV void group_body(X &x, const KArgs &a, int inst, int g) {
     real *lm = x.lds_mats();
     const int n_sw = (stages - 1) * dm.sw_stride, n_b = p.d() * p.nx() * p.nu();
     if (lds_mats) {
-        const real *src = a.mats + dm.mSweep + (long)root_stage * dm.sw_stride;
-        const real *srcB = a.mats + dm.mB;
+        const real *src = mats + dm.mSweep + (long)root_stage * dm.sw_stride;
+        const real *srcB = mats + dm.mB;
         x.each([&](int tid, TState<P> &) {
             for (int k = tid; k < n_sw; k += x.nthreads()) lm[k] = src[k];
             for (int k = tid; k < n_b; k += x.nthreads()) lm[n_sw + k] = srcB[k];

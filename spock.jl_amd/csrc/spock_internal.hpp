@@ -99,7 +99,8 @@ enum KFlags : unsigned {
 
 struct KArgs {
     Dims dm;
-    const real *mats;
+    const real *mats;           // the matrix pool; instance b reads mats + b * mats_stride (0: one pool shared by the batch)
+    long mats_stride;
     const real *z_in, *v_in;  // input iterate; instance b starts at z_in + b*stride_z, v_in + b*stride_v
     real *z_out, *v_out;      // zbar, vbar (same strides)
     real *z_next;             // SUB_BA only: where phase A of the NEXT iteration puts its part of the next zbar (third z buffer)
@@ -158,6 +159,7 @@ constexpr int kSpSums = 10;   // partial sums per workgroup of the flat / LOP ke
 struct SpArgs {
     Dims dm;
     const real *mats;
+    long mats_stride;          // as in KArgs
     Ctl *ctl;
     SpCtl *sp;
     // every vector is [batch][nr], nr = nz + nv, z part first
@@ -274,6 +276,7 @@ bool have_static_variant(int nx, int nu, int d, int ny);
 struct MpcArgs {
     Dims dm;
     const real *mats;
+    long mats_stride;
     const real *z;        // element e of instance b at z[b * stride_z + e * stride_e] (the u block of node 0 is the applied input)
     long stride_z, stride_e;
     real *x0;             // [batch][nx], updated in place: x0 <- A_w x0 + B_w u
@@ -295,6 +298,10 @@ struct BuildArgs {
     const double *B;     // [d][nx*nu]
     double *ws;          // workspace, build_ws_doubles(dm) doubles
     int *status;         // 0 ok, 1 Rtilde not positive definite
+    // batched builds (spock_update_dynamics_batch): workgroup b builds pool mats + b * mats_stride from A + b * d nx^2, B + b * d nx nu
+    // in workspace ws + b * build_ws_doubles(dm), status[b]
+    long mats_stride;
+    int n_inst;
 };
 
 int launch_build_riccati(const BuildArgs &a, void *stream);

@@ -210,9 +210,9 @@ __global__ void __launch_bounds__(512) spock_sp_lop_kernel(const SpArgs a) {
         const int stages = crown ? dm.t0 + 1 : (split ? dm.sub_stages : dm.N), nl_grp = group_threads_dev(p.d(), stages);
         for (int li = tm; li < nl_grp && tm < nteams; li += nteams) {
             const TeamNode tn = team_node(dm, p.d(), li, nl_grp, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0, stages, crown);
-            tlop(p, dm, (MatPtr)a.mats, A, B, B2, tn, r, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
+            tlop(p, dm, (MatPtr)(a.mats + (long)inst * a.mats_stride), A, B, B2, tn, r, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
         }
-    } else if (s.active) lop_local(p, dm, (MatPtr)a.mats, A, B, B2, s, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
+    } else if (s.active) lop_local(p, dm, (MatPtr)(a.mats + (long)inst * a.mats_stride), A, B, B2, s, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
     double mx[2] = {acc[2], acc[3]};
     block_reduce<2, false>(acc, red);
     __syncthreads();
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(kCtlThreads) spock_sp_ctl_kernel(const SpArgs 
         real xn = 0.;
         if (r < dm.nx) {
             if (t == 0) a.mpc_xt[((long)inst * (a.mpc_steps + 1)) * dm.nx + r] = x0[r];
-            xn = mpc_advance_row(dm, (MatPtr)a.mats, z, 1, x0, w, r);       // u = z[u_inds[1:nu]], x0 <- A_w x0 + B_w u
+            xn = mpc_advance_row(dm, (MatPtr)(a.mats + (long)inst * a.mats_stride), z, 1, x0, w, r);       // u = z[u_inds[1:nu]], x0 <- A_w x0 + B_w u
         }
         if (r < dm.nu) a.mpc_ut[((long)inst * a.mpc_steps + t) * dm.nu + r] = z[dm.zu + r];
         __syncthreads();   // every row has read the old x0 (and every thread the old `done`)
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(64) spock_mpc_advance_kernel(const MpcArgs a) 
     real xn = 0.;
     if (r < dm.nx) {
         if (a.t == 0) a.x_traj[((long)inst * (a.steps + 1)) * dm.nx + r] = x0[r];
-        xn = mpc_advance_row(dm, (MatPtr)a.mats, z, a.stride_e, x0, w, r);
+        xn = mpc_advance_row(dm, (MatPtr)(a.mats + (long)inst * a.mats_stride), z, a.stride_e, x0, w, r);
     }
     if (r < dm.nu) a.u_traj[((long)inst * a.steps + a.t) * dm.nu + r] = z[(long)(dm.zu + r) * a.stride_e];
     __syncthreads();   // every row has read the old x0

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(kSweepThreads) spock_sweep_kernel(const KArgs 
     real *zo = a.z_out + (long)inst * a.stride_z;
     const long gl_first = dm.first[root_stage + stages - 1] + (long)root_pos * ngl;
     real *qroot = a.qroot + (long)inst * dm.nsub * NX;
-    const MatPtr M = (MatPtr)a.mats;
+    const MatPtr M = (MatPtr)(a.mats + (long)inst * a.mats_stride);   // (per-instance pools: spock_update_dynamics_batch)
 
     // ---- control: finished instance -> exit; the crown also runs the termination test of the previous iteration (cp.jl:54-123)
     if (MODE == SW_CROWN && !(a.flags & F_SP) && !(a.flags & F_NO_CTL)) {

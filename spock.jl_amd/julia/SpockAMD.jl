@@ -17,8 +17,9 @@ struct GPU
     device::Int      # HIP device ordinal
     batch::Int       # independent instances held by the model (same problem data, own x0 and state)
     L_norm::Float64  # NaN: the reference's hard-coded 10.0 (cpock.jl:63) / 3.28 (models/spock.jl:64); < 0: closed form of ||L||^2
+    per_instance_dynamics::Bool   # every instance gets its own A_w, B_w through update_dynamics_batch! (Monte-Carlo draws)
 end
-GPU(; device = 0, batch = 1, L_norm = NaN) = GPU(device, batch, L_norm)
+GPU(; device = 0, batch = 1, L_norm = NaN, per_instance_dynamics = false) = GPU(device, batch, L_norm, per_instance_dynamics)
 
 struct SpockProblemC           # spock_problem_t (include/spock_amd.h)
     N::Cint; d::Cint; nx::Cint; nu::Cint; ny::Cint
@@ -35,7 +36,7 @@ end
 struct SpockOptionsC           # spock_options_t
     algorithm::Cint; device::Cint; batch::Cint; split_stage::Cint
     L_norm::Cdouble; max_iter::Cint; graph_iters::Cint; batch_layout::Cint
-    sp_variant::Cint; sp_max_backtrack::Cint; reserved_::Cint
+    sp_variant::Cint; sp_max_backtrack::Cint; per_instance_dynamics::Cint
 end
 
 struct SpockResultC            # spock_result_t
@@ -125,7 +126,7 @@ function build_model(scen_tree::AbstractScenarioTree, cost::AbstractCost, dynami
                           nQ, nR, nQN, pointer(Q), pointer(R), pointer(QN), pointer(E), pointer(F), pointer(b),
                           length(kinds), pointer(kinds), pointer(dims),
                           constraints.x_min, constraints.x_max, constraints.u_min, constraints.u_max, Cint(n_rms))
-        o = SpockOptionsC(Int(solver_options.algorithm), gpu.device, gpu.batch, 0, gpu.L_norm, 0, 0, 0, 0, 0, 0)   # sp_variant 0: as the reference
+        o = SpockOptionsC(Int(solver_options.algorithm), gpu.device, gpu.batch, 0, gpu.L_norm, 0, 0, 0, 0, 0, gpu.per_instance_dynamics ? 1 : 0)   # sp_variant 0: as the reference
         gpu_check(ccall((:spock_create, libspock_amd), Cint, (Ref{SpockProblemC}, Ref{SpockOptionsC}, Ref{Ptr{Cvoid}}), p, o, h))
     end
     sz = Ref{SpockSizesC}()
@@ -208,5 +209,17 @@ function update_dynamics!(model::GPU_SPOCK, dynamics::Dynamics)
     A = Vector{Float64}(vcat((vec(Matrix{Float64}(a)) for a in dynamics.A)...))     # [d][nx*nx], column-major per event
     B = Vector{Float64}(vcat((vec(Matrix{Float64}(b)) for b in dynamics.B)...))     # [d][nx*nu]
     GC.@preserve A B gpu_check(ccall((:spock_update_dynamics, libspock_amd), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), model.handle, A, B))
+    return nothing
+end
+
+"""One draw of the dynamics per instance of the batch (`dynamics[b].A[w]`, `.B[w]`): the builds run side by side on the GPU
+(spock_update_dynamics_batch); the model must have been built with `GPU(per_instance_dynamics = true)`.  The reference builds one
+model per draw (src/model.jl:273-297)."""
+function update_dynamics_batch!(model::GPU_SPOCK, dynamics::Vector{<:Dynamics})
+    length(dynamics) == model.batch || error("one Dynamics per instance expected")
+    A = Vector{Float64}(vcat((vec(Matrix{Float64}(a)) for dy in dynamics for a in dy.A)...))   # [batch][d][nx*nx]
+    B = Vector{Float64}(vcat((vec(Matrix{Float64}(b)) for dy in dynamics for b in dy.B)...))   # [batch][d][nx*nu]
+    status = zeros(Cint, model.batch)
+    GC.@preserve A B status gpu_check(ccall((:spock_update_dynamics_batch, libspock_amd), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}), model.handle, A, B, status))
     return nothing
 end

@@ -97,7 +97,7 @@ class Model:
     def __init__(self, flat: FlatProblem, options: SolverOptions, batch: int = 1, device: int = 0,
                  L_norm: float | str | None = None, max_iter: int = 0, split_stage: int = 0, graph_iters: int = 0,
                  lib_path: str | None = None, layout: str | int | None = None, dtype: str = "f64", sp_variant: int = 0,
-                 sp_max_backtrack: int = 0):
+                 sp_max_backtrack: int = 0, per_instance_dynamics: bool = False):
         if dtype not in ("f64", "f32"):
             raise ValueError("dtype must be 'f64' or 'f32'")
         self._lib = _lib.load_library(lib_path or (_lib.F32_LIB if dtype == "f32" else None))
@@ -112,7 +112,7 @@ class Model:
         lay = {None: 0, "auto": 0, "instance": 1, "instance-major": 1, "interleaved": 2, "element-major": 2}.get(layout, layout)
         op = _lib.Options(int(options.algorithm), int(device), self.batch, int(split_stage),
                           float("nan") if L_norm is None else (-1.0 if L_norm == "auto" else float(L_norm)), int(max_iter), int(graph_iters),
-                          int(lay), int(sp_variant), int(sp_max_backtrack), 0)
+                          int(lay), int(sp_variant), int(sp_max_backtrack), 1 if per_instance_dynamics else 0)
         h = C.c_void_p()
         _lib.check(self._lib, self._lib.spock_create(C.byref(pr), C.byref(op), C.byref(h)))
         self._h = h
@@ -197,6 +197,22 @@ class Model:
         _lib.check(self._lib, self._lib.spock_update_dynamics(self._h, _ptr(A), _ptr(B)))   # raises on failure: the model then keeps its dynamics
         fl.A, fl.B = A, B
 
+    def update_dynamics_batch(self, dynamics_list):
+        """One draw of the dynamics per instance (Monte-Carlo draws): instance b gets dynamics_list[b].A / .B; the device builds all of
+        them side by side (spock_update_dynamics_batch).  The model must have been built with per_instance_dynamics=True.  Returns the
+        per-instance status list (0 ok, 4 build failed: that instance keeps its previous dynamics; the call then raises, the statuses
+        stay in ``last_build_status``)."""
+        from .problem import _stack_colmajor
+        fl = self.problem_definition
+        if len(dynamics_list) != self.batch:
+            raise ValueError("one Dynamics per instance expected")
+        A = np.ascontiguousarray(np.concatenate([_stack_colmajor(dy.A, fl.nx, fl.nx) for dy in dynamics_list]))
+        B = np.ascontiguousarray(np.concatenate([_stack_colmajor(dy.B, fl.nx, fl.nu) for dy in dynamics_list]))
+        st = np.zeros(self.batch, dtype=np.int32)
+        self.last_build_status = st
+        _lib.check(self._lib, self._lib.spock_update_dynamics_batch(self._h, _ptr(A), _ptr(B), _ptr(st)))
+        return st.tolist()
+
     MODE_NAMES = {0: "full", 1: "sub_a", 2: "crown", 3: "sub_b", 5: "sub_ba", 8: "sub_b_lat", 9: "crown_a", 10: "i_up", 11: "i_down",
                   12: "lb", 13: "lba", 14: "la", 15: "la0", 16: "flat_a", 17: "flat_b", 18: "flat_b_sp", 19: "flat_ba"}
 
@@ -245,7 +261,8 @@ class Model:
 def build_model(scen_tree, cost, dynamics, rms, constraints, solver_options: SolverOptions = SolverOptions(CP, None),
                 **kw) -> Model:
     """model.jl:273-297.  Keyword extensions: batch, device, L_norm, max_iter, split_stage, graph_iters, lib_path, layout
-    ("instance" / "interleaved": how the batch is laid out in HBM; default: interleaved from 320 instances on), dtype ("f64", or
+    ("instance" / "interleaved": how the batch is laid out in HBM; default: interleaved from 320 instances on), per_instance_dynamics
+    (every instance its own matrix pool: Model.update_dynamics_batch gives each instance its own draw of A_w, B_w), dtype ("f64", or
     "f32": libspock_amd_f32.so, the same kernels in single precision -- the reference itself is Float64 only)."""
     if solver_options.algorithm not in (AlgorithmOptions.CP, AlgorithmOptions.SP):
         raise ValueError("This combination of solver options is not supported.")

@@ -225,9 +225,17 @@ struct EmuBuildExec {
     template <class F> void par(int n, F &&f) { for (int i = 0; i < n; ++i) f(i); }
     template <class F> void one(F &&f) { f(); }
 };
-int launch_build_riccati(const BuildArgs &a, void *) {
-    EmuBuildExec x;
-    build_riccati_body(x, a);
+int launch_build_riccati(const BuildArgs &a_in, void *) {
+    const int n = a_in.n_inst > 0 ? a_in.n_inst : 1;
+    const Dims &dm = a_in.dm;
+    for (int b = 0; b < n; ++b) {     // one "workgroup" per instance (spock_bkernels.hip)
+        BuildArgs a = a_in;
+        a.mats = a_in.mats + (long)b * a_in.mats_stride;
+        a.A = a_in.A + (long)b * dm.d * dm.nx * dm.nx; a.B = a_in.B + (long)b * dm.d * dm.nx * dm.nu;
+        a.ws = a_in.ws + (long)b * build_ws_doubles(dm); a.status = a_in.status + b;
+        EmuBuildExec x;
+        build_riccati_body(x, a);
+    }
     return 0;
 }
 
@@ -311,7 +319,7 @@ static int emu_lop(const SpArgs &a) {
                     for (int r = 0; r < T; ++r) {
                         const TeamNode tn = team_node(dm, p.d(), li, nl_grp, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0, stages, crown);
                         real acc[4] = {0., 0., 0., 0.};
-                        tlop(p, dm, (MatPtr)a.mats, A, B, B2, tn, r, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
+                        tlop(p, dm, (MatPtr)(a.mats + (long)inst * a.mats_stride), A, B, B2, tn, r, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
                         tot[0] += acc[0]; tot[1] += acc[1];
                         tot[2] = spk_max_nan(tot[2], acc[2]); tot[3] = spk_max_nan(tot[3], acc[3]);
                     }
@@ -321,7 +329,7 @@ static int emu_lop(const SpArgs &a) {
                 init_geometry(p, dm, tid, (split && !crown) ? dm.t0 : 0, (split && !crown) ? g : 0,
                               crown ? dm.t0 + 1 : (split ? dm.sub_stages : dm.N), crown, s);
                 real acc[4] = {0., 0., 0., 0.};
-                if (s.active) lop_local(p, dm, (MatPtr)a.mats, A, B, B2, s, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
+                if (s.active) lop_local(p, dm, (MatPtr)(a.mats + (long)inst * a.mats_stride), A, B, B2, s, a.ctl[inst].gamma, a.ctl[inst].sigma, acc);
                 tot[0] += acc[0]; tot[1] += acc[1];
                 tot[2] = spk_max_nan(tot[2], acc[2]); tot[3] = spk_max_nan(tot[3], acc[3]);
             }
@@ -359,7 +367,7 @@ int launch_sp(const SpArgs &a, void *) {
             std::vector<real> xn(dm.nx);
             for (int r = 0; r < dm.nx; ++r) {
                 if (t == 0) a.mpc_xt[((long)inst * (a.mpc_steps + 1)) * dm.nx + r] = x0[r];
-                xn[r] = mpc_advance_row(dm, (MatPtr)a.mats, z, 1, x0, w, r);
+                xn[r] = mpc_advance_row(dm, (MatPtr)(a.mats + (long)inst * a.mats_stride), z, 1, x0, w, r);
             }
             for (int r = 0; r < dm.nu; ++r) a.mpc_ut[((long)inst * a.mpc_steps + t) * dm.nu + r] = z[dm.zu + r];
             for (int r = 0; r < dm.nx; ++r) { x0[r] = xn[r]; a.mpc_xt[((long)inst * (a.mpc_steps + 1) + t + 1) * dm.nx + r] = xn[r]; }
@@ -423,7 +431,7 @@ int launch_mpc_advance(const MpcArgs &a, void *) {
         std::vector<real> xn(dm.nx);
         for (int r = 0; r < dm.nx; ++r) {
             if (a.t == 0) a.x_traj[((long)inst * (a.steps + 1)) * dm.nx + r] = x0[r];
-            xn[r] = mpc_advance_row(dm, (MatPtr)a.mats, z, a.stride_e, x0, w, r);
+            xn[r] = mpc_advance_row(dm, (MatPtr)(a.mats + (long)inst * a.mats_stride), z, a.stride_e, x0, w, r);
         }
         for (int r = 0; r < dm.nu; ++r) a.u_traj[((long)inst * a.steps + a.t) * dm.nu + r] = z[(long)(dm.zu + r) * a.stride_e];
         for (int r = 0; r < dm.nx; ++r) { x0[r] = xn[r]; a.x_traj[((long)inst * (a.steps + 1) + a.t + 1) * dm.nx + r] = xn[r]; }

@@ -597,6 +597,72 @@ def test_emulated_build_step_on_the_device(S, O, emu):
     m.close(); ref.close()
 
 
+def test_emulated_batched_draws_of_the_dynamics(S, O, emu):
+    """Monte-Carlo draws of the dynamics in ONE handle (north_star: "Monte-Carlo scenario-tree draws"): a batch built
+    with per_instance_dynamics, spock_update_dynamics_batch gives every instance its own A_w, B_w -- ricatti_offline (implicit_l.jl:46-97)
+    and the sweep matrices are built on the device for all instances side by side -- and each instance then solves ITS problem: against one
+    oracle per draw (CP iterates, SP residual log, the closed loop advancing with the instance's own A, B).  A draw whose build fails
+    leaves that instance, and only that one, with its previous dynamics."""
+    import dataclasses
+    for N, nx in ((6, 5), (5, 12)):
+        tree, cost, dyn, rms, con = S.get_server_heat_specs(N, nx, 2)
+        Bn = 3
+        rng = np.random.default_rng(7)
+        draws = [dataclasses.replace(dyn, A=[(0.85 + 0.05 * b) * a + 0.01 * rng.standard_normal(a.shape) for a in dyn.A],
+                                     B=[bb + 0.05 * rng.standard_normal(bb.shape) for bb in dyn.B]) for b in range(Bn)]
+        x0 = 0.1 * (1 + 0.1 * np.arange(Bn))[:, None] * np.cos(np.arange(nx))[None, :]
+        for alg, oalg in ((S.CP, O.CP), (S.SP, O.SP)):
+            m = S.build_model(tree, cost, dyn, rms, con, S.SolverOptions(alg, None), batch=Bn, per_instance_dynamics=True, max_iter=30, lib_path=emu)
+            assert m.sizes.interleaved == 0
+            assert m.update_dynamics_batch(draws) == [0] * Bn
+            rs = S.solve_model(m, x0, tol=1e-12, verbose=S.LOG)
+            for b in range(Bn):
+                o = O.Oracle(S.flatten_problem(tree, cost, draws[b], rms, con), oalg)
+                ro = o.solve(x0[b], tol=1e-12, verbose=O.LOG, max_iter=30, history=40)
+                h = m.history(b)
+                assert rs[b]["iterations"] == ro["iterations"] == 30
+                assert np.max(np.abs(h["xi"] - ro["hist_xi"]) / ro["hist_xi"]) <= (1e-9 if alg == S.CP else 1e-6)
+                if alg == S.CP:
+                    assert relerr(m.solver_state.z[b], o.z) <= 1e-9 and relerr(m.solver_state.v[b], o.v) <= 1e-9
+            m.close()
+        # closed loop: every instance advances with its own A_w, B_w; against one single-instance model per draw.  CP (whose
+        # trajectories are stable: same per-step iteration counts) and SP chained on the device (chaotic w.r.t. the rounding
+        # differences between the device build and the host build: every step converges, trajectories at the solve tolerance)
+        w = np.array([[0, 1, 1, 0], [1, 1, 0, 0], [0, 0, 1, 1]], dtype=np.int32)
+        for alg in (S.CP, S.SP):
+            m = S.build_model(tree, cost, dyn, rms, con, S.SolverOptions(alg, None), batch=Bn, per_instance_dynamics=True, lib_path=emu)
+            m.update_dynamics_batch(draws)
+            xt, ut, res = S.mpc_simulation(m, x0, w, tol=1e-3)
+            for b in range(Bn):
+                m1 = S.build_model(tree, cost, draws[b], rms, con, S.SolverOptions(alg, None), lib_path=emu)
+                x1, u1, r1 = S.mpc_simulation(m1, x0[b], w[b:b + 1], tol=1e-3)
+                assert all(r["status"] == 0 for r in res[b])
+                if alg == S.CP:
+                    assert [r["iterations"] for r in res[b]] == [r["iterations"] for r in r1[0]]
+                    assert np.max(np.abs(xt[b] - x1[0])) <= 1e-8 and np.max(np.abs(ut[b] - u1[0])) <= 1e-8
+                else:
+                    assert np.max(np.abs(xt[b] - x1[0])) <= 5e-2 and np.max(np.abs(ut[b] - u1[0])) <= 5e-2
+                m1.close()
+            if alg == S.CP:
+                m.close()
+        # one bad draw: the other instances get theirs, the bad one keeps what it had
+        z_before = None
+        S.solve_model(m, x0, tol=1e-3); m.reset()
+        rs0 = S.solve_model(m, x0, tol=1e-3); z_before = m.solver_state.z.copy()
+        bad = list(draws); bad[1] = dataclasses.replace(dyn, A=[1e160 * np.eye(nx) for _ in dyn.A])
+        with pytest.raises(S.SpockError) as err:
+            m.update_dynamics_batch(bad)
+        assert err.value.code == 4 and m.last_build_status.tolist() == [0, 4, 0]
+        m.reset(); S.solve_model(m, x0, tol=1e-3)
+        assert np.array_equal(m.solver_state.z, z_before)            # draws 0 and 2 are the same as before, draw 1 was rolled back
+        m.close()
+        # a handle without per-instance pools refuses
+        m = S.build_model(tree, cost, dyn, rms, con, batch=Bn, lib_path=emu)
+        with pytest.raises(S.SpockError):
+            m.update_dynamics_batch(draws)
+        m.close()
+
+
 # ---- element-major ("interleaved") batched regime: one lane per instance, one wave per tree node (spock_igroup.hpp) -----------
 @pytest.mark.parametrize("N,nu,B,kw", [(5, 5, 3, {}), (7, 2, 3, {}), (7, 5, 66, {}), (8, 2, 4, {"split_stage": 5}),
                                        (10, 5, 2, {"split_stage": 8}), (8, 2, 70, {"split_stage": 2}),
