@@ -483,6 +483,20 @@ def main(argv=None):
                                                          "frac": round(flops / (ms_it * 1e-3) / 1e12 / PEAKS[dt], 4)},
                                        "roofline_hbm": {"bound": "hbm", "achieved": round(b8d / (ms_it * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                         "frac": round(b8d / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_model": "SURVEY 8d bytes_CP", "bytes_per_iteration": b8d}}
+                    # the same with eight instances in flight (the sweeps' one-workgroup-per-subtree kernels then fill the chip four times over,
+                    # the flat node-local kernels stream): time per iteration of the batch, HBM fraction on SURVEY 8d's bytes_CP x 8
+                    B8 = 8
+                    mc = S.build_model(*sp5, S.SolverOptions(S.CP, None), batch=B8, device=dev_index, max_iter=24, graph_iters=24, L_norm="auto", dtype=dt)
+                    X8 = (1.0 + 0.01 * np.arange(B8))[:, None] * xc[None, :]
+                    S.solve_model(mc, X8, tol=0.0)
+                    r8 = S.solve_model(mc, X8, tol=0.0)
+                    mc.close()
+                    ms8 = r8[0]["solve_ms"] / r8[0]["iterations"]
+                    out["cfg5"][dt]["batch8"] = {"instances": B8, "ms_per_batch_iteration": round(ms8, 4), "ms_per_instance_iteration": round(ms8 / B8, 4),
+                                                 "roofline_hbm": {"bound": "hbm", "achieved": round(B8 * b8d / (ms8 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                                  "frac": round(B8 * b8d / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_model": "SURVEY 8d bytes_CP x instances"},
+                                                 "roofline_mfma": {"bound": "mfma", "achieved": round(B8 * flops / (ms8 * 1e-3) / 1e12, 3), "peak": PEAKS[dt], "unit": "TFLOP/s",
+                                                                   "frac": round(B8 * flops / (ms8 * 1e-3) / 1e12 / PEAKS[dt], 4)}}
                 out["cfg5"]["ms_per_iteration"] = out["cfg5"]["f64"]["ms_per_iteration"]
                 out["cfg5"]["roofline"] = dict(out["cfg5"]["f64"]["roofline_mfma"], kernel="S1 sweep levels on v_mfma_f64_16x16x4_f64 (spock_skernels.hip), node-local phases as flat kernels",
                                                traffic=None, note="a single instance: a chain of 2 x 14 dependent tree levels and five launch boundaries; see f64 / f32 for both rooflines")
