@@ -72,6 +72,37 @@ SPK_DEV real flat_team_sum(real val, int slot, int r, int T, real *red) {
     return s;
 }
 
+// The two SCALAR entries of a second-order-cone block and the cone's projection (implicit_l.jl:854-900, :752-810, :928-939;
+// risk_measures.jl:47-71): child cones (t = v6_j; ..., v5_j) with q = tau_j, leaf cones (t = v13; ..., v12) with q = s_leaf.  Inputs: zbar.q,
+// z.q, the two v entries, the squared norm `ssq` of the cone's VECTOR part (team sum).  sc_eff is what the vector entries are scaled
+// with: pj = sigma (t - sc_eff t) -- 1 when the point is kept (1.0 * t is exact), 0 when it projects to zero, tnew / |x| otherwise.
+// On the GPU ONE lane per cone evaluates this (lane q of the team owns cone q; its four inputs come from one gather each) and the
+// team reads sc_eff through a shuffle -- every lane evaluating every cone cost 4 x (sqrt + division + ~60 instructions) per node.
+struct ConeOut { real sc_eff, pA, pB, dvA, dvB, x2A, x2B, x1, dzq; };
+SPK_DEV ConeOut cone_eval(real zbq, real zq, real vA, real vB, real ssq, bool wz, bool noprox, const ProxScal &ps) {
+    const real sg = ps.sigma, isg = noprox ? 1. : ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg;
+    ConeOut o;
+    const real wq = wz ? zbq : 2. * zbq + -1. * zq;
+    o.dzq = zbq - zq;
+    real tA = (sg * (0.5 * wq) + vA) * isg, tB = (sg * (0.5 * wq) + vB) * isg;
+    real keep = 1., tnew = tA, sc = 1.;      // projected (t; x) = (tnew; sc * x) unless keep
+    if (!noprox) {
+        tB -= 0.5; tA += 0.5;                 // v5 -= 1/2, v6 += 1/2 (implicit_l.jl:928-939)
+        const real ss = tB * tB + ssq;
+        const real x_norm = sqrt(ss);
+        if (x_norm <= tA) { keep = 1.; }
+        else if (x_norm <= -tA) { keep = 0.; tnew = 0.; sc = 0.; }
+        else { keep = 0.; tnew = (tA + x_norm) / 2.; sc = tnew / x_norm; }
+    }
+    o.sc_eff = keep != 0. ? (real)1. : sc;
+    o.pA = noprox ? tA : sg * (tA - (keep != 0. ? tA : tnew));
+    o.pB = noprox ? tB : sg * (tB - (keep != 0. ? tB : sc * tB));
+    o.dvA = o.pA - vA; o.dvB = o.pB - vB;
+    o.x2A = 0.5 * o.dzq + nis * o.dvA; o.x2B = 0.5 * o.dzq + nis * o.dvB;
+    o.x1 = (0.5 * o.dvB + 0.5 * o.dvA) + nig * o.dzq;   // xi_1 on tau_j / s_leaf
+    return o;
+}
+
 template <class P, int SPM, int PASS>
 SPK_DEV void fb_node(const P &p, const Dims &dm, MatPtr M, const real *__restrict__ z, const real *__restrict__ v,
                      const real *zb, real *__restrict__ vo, const TeamNode &t, int r, int T, real *red, const ProxScal &ps,
@@ -106,11 +137,20 @@ SPK_DEV void fb_node(const P &p, const Dims &dm, MatPtr M, const real *__restric
         ui = zb[dm.zu + i * nu + r]; zui = z[dm.zu + i * nu + r]; v7u = v[dm.o7 + i * nxu + nx + r]; sr_r = SR[r + r * nu];
         SPK_UNROLL for (int c = 0; c < d; ++c) v4[c] = v[dm.o4 + (t.c0 + c - 1) * nu + r];
     }
-    real zbt[P::MAXD], zt_[P::MAXD], v6[P::MAXD], v5[P::MAXD], zbs2[P::MAXD], zs2[P::MAXD], v13[P::MAXD], v12[P::MAXD];
-    SPK_UNROLL for (int c = 0; c < d; ++c) {
-        const int j = t.c0 + c, jn = j - 1;
-        zbt[c] = zb[dm.zt + jn]; zt_[c] = z[dm.zt + jn]; v6[c] = v[dm.o6 + jn]; v5[c] = v[dm.o5 + jn];
-        if (leaf) { const int li = j - dm.nn; zbs2[c] = zb[dm.zs + j]; zs2[c] = z[dm.zs + j]; v13[c] = v[dm.o13 + li]; v12[c] = v[dm.o12 + li]; }
+    // the cones' scalar entries: cone q < d is child q's (zbar.tau, z.tau, v6, v5), cone d + c leaf child c's (zbar.s, z.s, v13, v12).
+    // GPU: lane q of the team loads cone q's four values (one gather per kind); host emulation: every lane reads what it needs below
+    const int ncones = leaf ? 2 * d : d;
+    auto cone_idx = [&](int q, int &iq, int &iA, int &iB) {
+        const int cc = q < d ? q : q - d, j = t.c0 + cc;
+        if (q < d) { iq = dm.zt + j - 1; iA = dm.o6 + j - 1; iB = dm.o5 + j - 1; }
+        else { iq = dm.zs + j; iA = dm.o13 + (j - dm.nn); iB = dm.o12 + (j - dm.nn); }
+    };
+    int my_iq = 0, my_iA = 0, my_iB = 0;
+    real my_zbq = 0., my_zq = 0., my_vA = 0., my_vB = 0.;
+    const bool cone_owner = r < ncones;
+    if (PASS == 0 && cone_owner) {
+        cone_idx(r, my_iq, my_iA, my_iB);
+        my_zbq = zb[my_iq]; my_zq = z[my_iq]; my_vA = v[my_iA]; my_vB = v[my_iB];
     }
     // ---- w = 2 zbar - z (cp.jl:23-24), dz = zbar - z, the pre-prox value of every owned v entry (tb_p1)
     real wy = 0., dzy = 0.;
@@ -210,35 +250,43 @@ SPK_DEV void fb_node(const P &p, const Dims &dm, MatPtr M, const real *__restric
         m2 = spk_max_nan(m2, fabs(lxu));
         acc_v(dm.o7 + i * nxu + nx + r, ltu, lxu);
     }
-    // per child: (v6; v3, v4, v5) in SOC(nx + nu + 2)   (implicit_l.jl:854-900, :928-933)
+    // the cones' scalar entries and projections: one lane per cone (GPU), sc_eff of every cone to every lane
+    real sc_eff[2 * P::MAXD];
+    auto cone_owner_work = [&](const ConeOut &co, int iq, int iA, int iB) {
+        vo[iA] = co.pA; vo[iB] = co.pB;
+        m2 = spk_max_nan(m2, fabs(co.x2A)); m2 = spk_max_nan(m2, fabs(co.x2B));
+        m1 = spk_max_nan(m1, fabs(co.x1));
+        acc_v(iA, co.dvA, co.x2A); acc_v(iB, co.dvB, co.x2B); acc_z(iq, co.dzq, co.x1);
+        if (wx) m3 = spk_max_nan(m3, fabs((0.5 * co.x2B + 0.5 * co.x2A) + co.x1));
+    };
+#ifndef SPOCK_HOST_EMU
+    if (PASS == 0) {
+        real my_ssq = ssq[0];
+        SPK_UNROLL for (int q = 1; q < 2 * d; ++q) my_ssq = (r == q) ? ssq[q] : my_ssq;
+        const ConeOut co = cone_eval(my_zbq, my_zq, my_vA, my_vB, my_ssq, wz, noprox, ps);
+        if (cone_owner) cone_owner_work(co, my_iq, my_iA, my_iB);
+        const int team_base = (int)(threadIdx.x & 63u) - r;        // first lane of this team inside its wave
+        SPK_UNROLL for (int q = 0; q < 2 * d; ++q) sc_eff[q] = __shfl(co.sc_eff, team_base + q, 64);
+    } else
+#endif
+    {
+        SPK_UNROLL for (int q = 0; q < 2 * d; ++q) {
+            sc_eff[q] = 1.;
+            if (q >= ncones) continue;
+            int iq, iA, iB;
+            cone_idx(q, iq, iA, iB);
+            const ConeOut co = cone_eval(zb[iq], z[iq], v[iA], v[iB], ssq[q], wz, noprox, ps);
+            sc_eff[q] = co.sc_eff;
+            if (r == q) cone_owner_work(co, iq, iA, iB);
+        }
+    }
+    // per child: the vector entries of (v6; v3, v4, v5) in SOC(nx + nu + 2)   (implicit_l.jl:854-900)
     SPK_UNROLL for (int c = 0; c < d; ++c) {
         const int j = t.c0 + c, jn = j - 1;
-        const real wt = wz ? zbt[c] : 2. * zbt[c] + -1. * zt_[c], dzt = zbt[c] - zt_[c];
-        real t6 = (sg * (0.5 * wt) + v6[c]) * isg, t5 = (sg * (0.5 * wt) + v5[c]) * isg;
-        real keep = 1., tnew = t6, sc = 1.;      // projected (t; x) = (tnew; sc * x) unless keep
-        if (!noprox) {
-            t5 -= 0.5; t6 += 0.5;
-            const real ss = t5 * t5 + ssq[c];
-            const real x_norm = sqrt(ss);
-            if (x_norm <= t6) { keep = 1.; }
-            else if (x_norm <= -t6) { keep = 0.; tnew = 0.; sc = 0.; }
-            else { keep = 0.; tnew = (t6 + x_norm) / 2.; sc = tnew / x_norm; }
-        }
-        const real p6 = noprox ? t6 : sg * (t6 - (keep != 0. ? t6 : tnew));
-        const real p5 = noprox ? t5 : sg * (t5 - (keep != 0. ? t5 : sc * t5));
-        const real dv6 = p6 - v6[c], dv5 = p5 - v5[c];
-        const real x26 = 0.5 * dzt + nis * dv6, x25 = 0.5 * dzt + nis * dv5;
-        if (r == 0) {
-            vo[dm.o6 + jn] = p6; vo[dm.o5 + jn] = p5;
-            m2 = spk_max_nan(m2, fabs(x26)); m2 = spk_max_nan(m2, fabs(x25));
-            const real x1t = (0.5 * dv5 + 0.5 * dv6) + nig * dzt;   // xi_1 on tau_j
-            m1 = spk_max_nan(m1, fabs(x1t));
-            acc_v(dm.o6 + jn, dv6, x26); acc_v(dm.o5 + jn, dv5, x25); acc_z(dm.zt + jn, dzt, x1t);
-            if (wx) m3 = spk_max_nan(m3, fabs((0.5 * x25 + 0.5 * x26) + x1t));
-        }
+        const real sc = sc_eff[c];
         if (hx) {
             const real tt = t3[c];
-            const real pj = noprox ? tt : sg * (tt - (keep != 0. ? tt : sc * tt));
+            const real pj = noprox ? tt : sg * (tt - sc * tt);
             vo[dm.o3 + jn * nx + r] = pj;
             const real dv = pj - v3[c], xx = l3[c] + nis * dv;
             m2 = spk_max_nan(m2, fabs(xx));
@@ -247,55 +295,31 @@ SPK_DEV void fb_node(const P &p, const Dims &dm, MatPtr M, const real *__restric
         }
         if (hu) {
             const real tt = t4[c];
-            const real pj = noprox ? tt : sg * (tt - (keep != 0. ? tt : sc * tt));
+            const real pj = noprox ? tt : sg * (tt - sc * tt);
             vo[dm.o4 + jn * nu + r] = pj;
             const real dv = pj - v4[c], xx = l4[c] + nis * dv;
             m2 = spk_max_nan(m2, fabs(xx));
             acc_v(dm.o4 + jn * nu + r, dv, xx);
             ltu += sr_r * dv; lxu += sr_r * xx;
         }
-        // leaf child: (v13; v11, v12) in SOC(nx + 2), v14 in the x box   (implicit_l.jl:752-810, :934-939)
-        if (leaf) {
+        // leaf child: the vector entries of (v13; v11, v12) in SOC(nx + 2), v14 in the x box   (implicit_l.jl:752-810)
+        if (leaf && hx) {
             const int li = j - dm.nn;
-            const real ws2 = wz ? zbs2[c] : 2. * zbs2[c] + -1. * zs2[c], dzs2 = zbs2[c] - zs2[c];
-            real t13 = (sg * (0.5 * ws2) + v13[c]) * isg, t12 = (sg * (0.5 * ws2) + v12[c]) * isg;
-            real keep2 = 1., tnew2 = t13, sc2 = 1.;
-            if (!noprox) {
-                t12 -= 0.5; t13 += 0.5;
-                const real ss = t12 * t12 + ssq[d + c];
-                const real x_norm = sqrt(ss);
-                if (x_norm <= t13) { keep2 = 1.; }
-                else if (x_norm <= -t13) { keep2 = 0.; tnew2 = 0.; sc2 = 0.; }
-                else { keep2 = 0.; tnew2 = (t13 + x_norm) / 2.; sc2 = tnew2 / x_norm; }
-            }
-            const real p13 = noprox ? t13 : sg * (t13 - (keep2 != 0. ? t13 : tnew2));
-            const real p12 = noprox ? t12 : sg * (t12 - (keep2 != 0. ? t12 : sc2 * t12));
-            const real dv13 = p13 - v13[c], dv12 = p12 - v12[c];
-            const real x213 = 0.5 * dzs2 + nis * dv13, x212 = 0.5 * dzs2 + nis * dv12;
-            if (r == 0) {
-                vo[dm.o13 + li] = p13; vo[dm.o12 + li] = p12;
-                m2 = spk_max_nan(m2, fabs(x213)); m2 = spk_max_nan(m2, fabs(x212));
-                const real x1s2 = (0.5 * dv12 + 0.5 * dv13) + nig * dzs2;   // xi_1 on s_leaf
-                m1 = spk_max_nan(m1, fabs(x1s2));
-                acc_v(dm.o13 + li, dv13, x213); acc_v(dm.o12 + li, dv12, x212); acc_z(dm.zs + j, dzs2, x1s2);
-                if (wx) m3 = spk_max_nan(m3, fabs((0.5 * x212 + 0.5 * x213) + x1s2));
-            }
-            if (hx) {
-                const real tt = t11[c];
-                const real p11 = noprox ? tt : sg * (tt - (keep2 != 0. ? tt : sc2 * tt));
-                vo[dm.o11 + li * nx + r] = p11;
-                const real dv11 = p11 - v11[c], x211 = l11[c] + nis * dv11;
-                m2 = spk_max_nan(m2, fabs(x211));
-                const real q14 = t14[c];
-                const real p14 = noprox ? q14 : sg * (q14 - spk_clamp(q14, dm.x_min, dm.x_max));
-                vo[dm.o14 + li * nx + r] = p14;
-                const real dv14 = p14 - v14[c], x214 = dl[c] + nis * dv14;
-                m2 = spk_max_nan(m2, fabs(x214));
-                const real x1 = (dv14 + sn_r * dv11) + nig * dl[c];   // x_leaf = v14 + sqrtQN v11
-                m1 = spk_max_nan(m1, fabs(x1));
-                acc_v(dm.o11 + li * nx + r, dv11, x211); acc_v(dm.o14 + li * nx + r, dv14, x214); acc_z(dm.zx + j * nx + r, dl[c], x1);
-                if (wx) m3 = spk_max_nan(m3, fabs((x214 + sn_r * x211) + x1));
-            }
+            const real sc2 = sc_eff[d + c];
+            const real tt = t11[c];
+            const real p11 = noprox ? tt : sg * (tt - sc2 * tt);
+            vo[dm.o11 + li * nx + r] = p11;
+            const real dv11 = p11 - v11[c], x211 = l11[c] + nis * dv11;
+            m2 = spk_max_nan(m2, fabs(x211));
+            const real q14 = t14[c];
+            const real p14 = noprox ? q14 : sg * (q14 - spk_clamp(q14, dm.x_min, dm.x_max));
+            vo[dm.o14 + li * nx + r] = p14;
+            const real dv14 = p14 - v14[c], x214 = dl[c] + nis * dv14;
+            m2 = spk_max_nan(m2, fabs(x214));
+            const real x1 = (dv14 + sn_r * dv11) + nig * dl[c];   // x_leaf = v14 + sqrtQN v11
+            m1 = spk_max_nan(m1, fabs(x1));
+            acc_v(dm.o11 + li * nx + r, dv11, x211); acc_v(dm.o14 + li * nx + r, dv14, x214); acc_z(dm.zx + j * nx + r, dl[c], x1);
+            if (wx) m3 = spk_max_nan(m3, fabs((x214 + sn_r * x211) + x1));
         }
     }
     if (hx) {

@@ -43,8 +43,10 @@ SPK_DEV int team_scratch_doubles(int nu, int m, int d, int T) { return m + nu + 
 // ---------------------------------------------------------------------------------------------------
 // phase A, part 1: zbar0 = (-gamma) L'v + z on the lane's elements; publish [y; s_ch; tau_ch] and ubar
 template <class P>
+// (S, XL restrict-qualified: what the lanes publish does not alias the iterate they read, so the loads of the u and [y; s; tau] parts
+//  are not held back behind the stores of the x part)
 SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const real *__restrict__ z, const real *__restrict__ v,
-                   real *__restrict__ zo, const TeamNode &t, int r, int T, real *S, real *XL, real gamma, unsigned flags,
+                   real *__restrict__ zo, const TeamNode &t, int r, int T, real *__restrict__ S, real *__restrict__ XL, real gamma, unsigned flags,
                    TLReg<P> &g, const real *v2x = nullptr) {
     if (!t.active) return;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), nxu = nx + nu, m = ny + 2 * d;
@@ -73,17 +75,22 @@ SPK_DEV void ta_p1(const P &p, const Dims &dm, MatPtr M, const real *__restrict_
         if (raw) zo[dm.zu + i * nu + r] = g.ub; else ubs[r] = g.ub;
     }
     for (int e = r; e < m; e += T) {   // [y_i ; s_children ; tau_children]  (implicit_l.jl:423-448)
+        // every lane first forms the indices of its three operands and loads them -- one round trip to memory for the whole vector --
+        // then applies its entry's formula (as three divergent branches with their own loads the entries waited for three)
+        const bool isy = e < ny, iss = !isy && e < ny + d;
+        const int cc = isy ? 0 : (iss ? e - ny : e - ny - d), j = t.c0 + cc;
+        const bool use_v2x = iss && v2x && t.kids_gleaf, sleaf = iss && j >= dm.nn;
+        const int iA = isy ? i * ny + e : (iss ? (sleaf ? dm.o12 + (j - dm.nn) : dm.o2 + j) : dm.o5 + j - 1);
+        const int iB = isy ? dm.o2 + i : (iss ? (sleaf ? dm.o13 + (j - dm.nn) : dm.o2 + j) : dm.o6 + j - 1);
+        const int iZ = isy ? dm.zy + i * ny + e : (iss ? dm.zs + j : dm.zt + j - 1);
+        const real a = v[iA], b = v[iB], zz = z[iZ];
         real val;
-        if (e < ny) val = mg * (v[i * ny + e] - bb[e] * v[dm.o2 + i]) + z[dm.zy + i * ny + e];
-        else if (e < ny + d) {
-            const int j = t.c0 + (e - ny);
-            const real ls = (v2x && t.kids_gleaf) ? v2x[t.pos * d + (e - ny)]   // crown workgroup of the fused B+A kernel
-                              : (j < dm.nn) ? v[dm.o2 + j] : 0.5 * v[dm.o12 + (j - dm.nn)] + 0.5 * v[dm.o13 + (j - dm.nn)];
-            val = mg * ls + z[dm.zs + j];
-        } else {
-            const int j = t.c0 + (e - ny - d);
-            val = mg * (0.5 * v[dm.o5 + j - 1] + 0.5 * v[dm.o6 + j - 1]) + z[dm.zt + j - 1];
-        }
+        if (isy) val = mg * (a - bb[e] * b) + zz;
+        else if (iss) {
+            const real ls = use_v2x ? v2x[t.pos * d + cc]   // crown workgroup of the fused B+A kernel / flat B+A: recomputed by the parent's team
+                                    : (sleaf ? 0.5 * a + 0.5 * b : a);
+            val = mg * ls + zz;
+        } else val = mg * (0.5 * a + 0.5 * b) + zz;
         if (raw) {
             if (e < ny) zo[dm.zy + i * ny + e] = val;
             else if (e < ny + d) zo[dm.zs + t.c0 + (e - ny)] = val;
@@ -112,20 +119,26 @@ SPK_DEV void ta_p2(const P &p, const Dims &dm, MatPtr M, real *__restrict__ zo, 
     const int i = t.node;
     const real *vec = S, *ubs = S + m;
     const MatPtr LS = M + dm.mLs + (dm.nRm > 1 ? i * m * m : 0);
+#ifndef FLAT_EXP
+#define FLAT_EXP 0
+#endif
     for (int e = r; e < m; e += T) {   // implicit_l.jl:708-726
-        const real a = lmLS ? tl_rowdot(lmLS + e, m, vec, m) : tl_rowdot(LS + e, m, vec, m);
+        const real a = (FLAT_EXP == 4) ? vec[e] : lmLS ? tl_rowdot(lmLS + e, m, vec, m) : tl_rowdot(LS + e, m, vec, m);
         if (e < ny) zo[dm.zy + i * ny + e] = a;
         else if (e < ny + d) zo[dm.zs + t.c0 + (e - ny)] = a;
         else zo[dm.zt + t.c0 + (e - ny - d) - 1] = a;
     }
     if (r < nx) {
         const MatPtr Ut = M + dm.mU + t.stage * nx * nu;
-        const real a = lmU ? tl_rowdot(lmU + r, nx, ubs, nu) : tl_rowdot(Ut + r, nx, ubs, nu);
-        cq[r] = a - g.xb;
+        const real a = (FLAT_EXP == 4) ? ubs[0] : lmU ? tl_rowdot(lmU + r, nx, ubs, nu) : tl_rowdot(Ut + r, nx, ubs, nu);
+        if (FLAT_EXP != 3) cq[r] = a - g.xb;
+        else if (a == 1.2345e300) cq[r] = a;
     }
     if (r < nu) {
         const MatPtr Ri = M + dm.mRinv + t.stage * nu * nu;
-        ce[r] = lmRi ? tl_rowdot(lmRi + r, nu, ubs, nu) : tl_rowdot(Ri + r, nu, ubs, nu);
+        const real ev = (FLAT_EXP == 4) ? ubs[r] : lmRi ? tl_rowdot(lmRi + r, nu, ubs, nu) : tl_rowdot(Ri + r, nu, ubs, nu);
+        if (FLAT_EXP != 3) ce[r] = ev;
+        else if (ev == 1.2345e300) ce[r] = ev;
     }
 }
 
