@@ -254,10 +254,10 @@ SPK_DEV void fb_node(const P &p, const Dims &dm, MatPtr M, const real *__restric
     real sc_eff[2 * P::MAXD];
     auto cone_owner_work = [&](const ConeOut &co, int iq, int iA, int iB) {
         vo[iA] = co.pA; vo[iB] = co.pB;
-        m2 = spk_max_nan(m2, fabs(co.x2A)); m2 = spk_max_nan(m2, fabs(co.x2B));
-        m1 = spk_max_nan(m1, fabs(co.x1));
+        m2 = spk_max_nan(m2, (real)fabs(co.x2A)); m2 = spk_max_nan(m2, (real)fabs(co.x2B));
+        m1 = spk_max_nan(m1, (real)fabs(co.x1));
         acc_v(iA, co.dvA, co.x2A); acc_v(iB, co.dvB, co.x2B); acc_z(iq, co.dzq, co.x1);
-        if (wx) m3 = spk_max_nan(m3, fabs((0.5 * co.x2B + 0.5 * co.x2A) + co.x1));
+        if (wx) m3 = spk_max_nan(m3, (real)fabs((0.5 * co.x2B + 0.5 * co.x2A) + co.x1));
     };
 #ifndef SPOCK_HOST_EMU
     if (PASS == 0) {

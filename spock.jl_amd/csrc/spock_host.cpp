@@ -395,6 +395,22 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
 
     int t0 = split_stage > 0 ? split_stage : choose_split_stage(N, d, nx, nu, batch);
     if (t0 < 0) { unsupported = true; return "tree does not fit the two-level subtree tiling"; }
+    {   // Small trees of the shapes with matrix-core sweep kernels (spock_skernels.hip): split them as well.  The whole-tree kernel runs
+        // its sweep levels as scalar lane-team levels with the matrices fetched from L2 (nx = nu = 50, N = 7: 1.7 ms per SP iteration) and,
+        // once the tree's sweep vectors pass the LDS (N = 8 at nx = 50), falls back to one thread per node (scaling.jl N = 8: 3.6 s);
+        // flat node-local kernels + UP / CROWN / DOWN cost five launches and ~0.2 ms per SP iteration whatever the tree's size.
+        auto shared_diag = [&](const std::vector<double> &m, int cnt, int n) {
+            if (cnt != 1) return false;
+            for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) if (i != j && m[(size_t)i + (size_t)j * n] != 0.) return false;
+            return true;
+        };
+        bool soc = false;
+        for (int k : hp.cone_kind) soc = soc || k == 4;
+        const bool sweep_shape = (nx == 64 && nu == 16 && d == 2) || (nx == 20 && nu == 20 && (d == 2 || d == 3)) || (nx == 50 && nu == 50 && d == 2);
+        if (split_stage <= 0 && t0 == 0 && N >= 3 && sweep_shape && !soc && !std::getenv("SPOCK_AMD_NO_SMALL_SPLIT") &&
+            shared_diag(hp.Q, hp.nQ, nx) && shared_diag(hp.R, hp.nR, nu) && shared_diag(hp.QN, hp.nQN, nx))
+            t0 = (N - 1) / 2 < 1 ? 1 : (N - 1) / 2;
+    }
     if (t0 > 0) {
         if (t0 > N - 2) return "split_stage must leave subtrees of at least two stages";
         const int lim = (144 * 1024 / 8) / nx < 512 ? (144 * 1024 / 8) / nx : 512;

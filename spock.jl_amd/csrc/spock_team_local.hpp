@@ -119,26 +119,20 @@ SPK_DEV void ta_p2(const P &p, const Dims &dm, MatPtr M, real *__restrict__ zo, 
     const int i = t.node;
     const real *vec = S, *ubs = S + m;
     const MatPtr LS = M + dm.mLs + (dm.nRm > 1 ? i * m * m : 0);
-#ifndef FLAT_EXP
-#define FLAT_EXP 0
-#endif
     for (int e = r; e < m; e += T) {   // implicit_l.jl:708-726
-        const real a = (FLAT_EXP == 4) ? vec[e] : lmLS ? tl_rowdot(lmLS + e, m, vec, m) : tl_rowdot(LS + e, m, vec, m);
+        const real a = lmLS ? tl_rowdot(lmLS + e, m, vec, m) : tl_rowdot(LS + e, m, vec, m);
         if (e < ny) zo[dm.zy + i * ny + e] = a;
         else if (e < ny + d) zo[dm.zs + t.c0 + (e - ny)] = a;
         else zo[dm.zt + t.c0 + (e - ny - d) - 1] = a;
     }
     if (r < nx) {
         const MatPtr Ut = M + dm.mU + t.stage * nx * nu;
-        const real a = (FLAT_EXP == 4) ? ubs[0] : lmU ? tl_rowdot(lmU + r, nx, ubs, nu) : tl_rowdot(Ut + r, nx, ubs, nu);
-        if (FLAT_EXP != 3) cq[r] = a - g.xb;
-        else if (a == 1.2345e300) cq[r] = a;
+        const real a = lmU ? tl_rowdot(lmU + r, nx, ubs, nu) : tl_rowdot(Ut + r, nx, ubs, nu);
+        cq[r] = a - g.xb;
     }
     if (r < nu) {
         const MatPtr Ri = M + dm.mRinv + t.stage * nu * nu;
-        const real ev = (FLAT_EXP == 4) ? ubs[r] : lmRi ? tl_rowdot(lmRi + r, nu, ubs, nu) : tl_rowdot(Ri + r, nu, ubs, nu);
-        if (FLAT_EXP != 3) ce[r] = ev;
-        else if (ev == 1.2345e300) ce[r] = ev;
+        ce[r] = lmRi ? tl_rowdot(lmRi + r, nu, ubs, nu) : tl_rowdot(Ri + r, nu, ubs, nu);
     }
 }
 

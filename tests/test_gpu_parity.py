@@ -755,3 +755,29 @@ def test_batched_draws_of_the_dynamics(S, O):
         with pytest.raises(S.SpockError):
             m.update_dynamics_batch(draws)
         m.close()
+
+
+@pytest.mark.parametrize("nx,nu,d", [(20, 20, 2), (20, 20, 3), (64, 16, 2), (50, 50, 2)])
+def test_small_trees_on_the_sweep_kernels(S, O, nx, nu, d):
+    """Trees of 3 - 6 stages at the shapes with matrix-core sweep kernels: they are split like the large ones (a one-node crown over
+    two-stage subtrees at N = 3) and run flat node-local kernels + UP / CROWN / DOWN instead of the whole-tree kernel (scaling.jl's
+    N = 3 .. 8 at nx = 50 were 31 .. 3600 ms there).  CP iterates and the first SP iterations against the oracle."""
+    for N in (3, 4, 6) if d == 2 else (3, 5):
+        specs = S.get_random_linear_specs(N, nx, nu, d=d) if nx == 64 else S.get_server_heat_specs(N, nx, d, p_ref=None if d == 2 else [0.2, 0.3, 0.5])
+        flat = S.flatten_problem(*specs)
+        x0 = 0.1 * np.cos(np.arange(nx))
+        m = S.build_model(*specs, L_norm="auto", max_iter=25)
+        assert m.sizes.split_stage >= 1 and [n for n, _, _ in m.profile_sequence(1)] == ["sub_a", "crown", "sub_b", "flat_ba"]
+        m.reset()
+        r = S.solve_model(m, x0, tol=0.0)
+        o = O.Oracle(flat, O.CP); o.L_norm = m.solver_state.L_norm
+        o.solve(x0, tol=0.0, max_iter=25)
+        assert r["iterations"] == 25 and relerr(m.solver_state.z, o.z) <= 1e-10 and relerr(m.solver_state.v, o.v) <= 1e-10, N
+        m.close()
+        ms = S.build_model(*specs, S.SolverOptions(S.SP, None), L_norm="auto", max_iter=8)
+        S.solve_model(ms, x0, tol=1e-12, verbose=S.LOG)
+        os_ = O.Oracle(flat, O.SP); os_.L_norm = ms.solver_state.L_norm
+        ro = os_.solve(x0, tol=1e-12, verbose=O.LOG, max_iter=8, history=12)
+        h = ms.history()
+        assert np.max(np.abs(h["xi"] - ro["hist_xi"]) / ro["hist_xi"]) <= 1e-8 and np.array_equal(h["backtrack"], ro["hist_backtrack"]), N
+        ms.close()
