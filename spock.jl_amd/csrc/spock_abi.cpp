@@ -194,10 +194,12 @@ int launch_cp_iteration(spock_handle_s *h, int k, unsigned flags = 0, void *stre
         if (!dm.ilv_stream) { if (e == 0) e = launch_group(MODE_SUB_BA, a, stream); return e; }
         // level-streaming kernels (spock_ilevel.hpp) for the stages t0 .. N-2: phase B top-down, the bottom stage fused with the
         // next phase A and the backward step, then the next phase A + backward step bottom-up
-        for (int t = dm.t0; t <= dm.N - 3 && e == 0; ++t) { a.grp_level = t; e = launch_group(MODE_LB, a, stream); }
-        a.grp_level = dm.N - 2;
-        if (e == 0) e = launch_group(MODE_LBA, a, stream);
-        for (int t = dm.N - 3; t >= dm.t0 && e == 0; --t) { a.grp_level = t; e = launch_group(MODE_LA, a, stream); }
+        // (ilv_fuse2: the stages N-3 and N-2 as one launch, LBA2 -- LB and LA then stop one stage higher)
+        const int t_lb = dm.ilv_fuse2 ? dm.N - 4 : dm.N - 3;
+        for (int t = dm.t0; t <= t_lb && e == 0; ++t) { a.grp_level = t; e = launch_group(MODE_LB, a, stream); }
+        a.grp_level = dm.ilv_fuse2 ? dm.N - 3 : dm.N - 2;
+        if (e == 0) e = launch_group(dm.ilv_fuse2 ? MODE_LBA2 : MODE_LBA, a, stream);
+        for (int t = t_lb; t >= dm.t0 && e == 0; --t) { a.grp_level = t; e = launch_group(MODE_LA, a, stream); }
         return e;
     }
     int e = 0;
@@ -1290,9 +1292,10 @@ static int profile_impl(spock_handle_t h, int32_t reps, double *avg_ms, int32_t 
         push(MODE_CROWN, it);
         if (h->ilv) for (int lv = 1; lv <= pdm.n_lv - 2; ++lv) push(MODE_I_DOWN, it, lv);
         if (stream_lv) {
-            for (int t = pdm.t0; t <= pdm.N - 3; ++t) push(MODE_LB, it, t);
-            push(MODE_LBA, it, pdm.N - 2);
-            for (int t = pdm.N - 3; t >= pdm.t0; --t) push(MODE_LA, it, t);
+            const int t_lb = pdm.ilv_fuse2 ? pdm.N - 4 : pdm.N - 3;
+            for (int t = pdm.t0; t <= t_lb; ++t) push(MODE_LB, it, t);
+            if (pdm.ilv_fuse2) push(MODE_LBA2, it, pdm.N - 3); else push(MODE_LBA, it, pdm.N - 2);
+            for (int t = t_lb; t >= pdm.t0; --t) push(MODE_LA, it, t);
         } else push(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), it);
     }
     std::vector<void *> ev(seq.size() * 2, nullptr);

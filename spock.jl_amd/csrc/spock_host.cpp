@@ -172,8 +172,10 @@ static int ilv_group_span(int d, int nx) {
 
 // level-streaming kernels: waves per workgroup and LDS exchange rows (role waves hand their partial results to the finishing
 // waves through rows of 64 doubles, double-buffered over the nodes of the chunk)
-int ilevel_waves(int mode, const Dims &dm) { return mode == MODE_LBA ? 2 + 2 * dm.d : (mode == MODE_LB ? 2 + dm.d : 4); }   // X, R, C_c (, L_c)
+int ilevel_waves(int mode, const Dims &dm) { return (mode == MODE_LBA || mode == MODE_LBA2) ? 2 + 2 * dm.d : (mode == MODE_LB ? 2 + dm.d : 4); }   // X, R, C_c (, L_c)
 int ilevel_ex_doubles(int mode, const Dims &dm, int want_xi) {
+    if (mode == MODE_LBA2)   // + x and q of the children, c_i / e_i and [y; s_ch; tau_ch] of the parent (double-buffered over the parents)
+        return (2 * lba_exchange_rows(dm.nx, dm.nu, dm.d, want_xi != 0) + 2 * dm.d * dm.nx + 2 * (dm.nx + dm.nu) + 2 * (dm.ny + 2 * dm.d)) * 64;
     if (mode == MODE_LBA) return 2 * lba_exchange_rows(dm.nx, dm.nu, dm.d, want_xi != 0) * 64;
     if (mode == MODE_LB) return 2 * lb_exchange_rows(dm.nx, dm.nu, dm.d, want_xi != 0) * 64;
     return 0;
@@ -192,7 +194,7 @@ IlvGeo ilv_geometry(int mode, const Dims &dm, int level, int want_xi) {
     if (mode == MODE_FINALIZE) { g.threads = 64; g.grid_x = 1; }
     else if (mode == MODE_ICROWN_A) g.grid_x = g.n_cchunks;
     else if (mode == MODE_SUB_A || mode == MODE_SUB_BA) { g.grid_x = dm.nsub; g.ex_doubles = sub_nl * nx * 64; }
-    else if (mode == MODE_LB || mode == MODE_LBA || mode == MODE_LA || mode == MODE_LA0) {   // `level` = the tree stage
+    else if (mode == MODE_LB || mode == MODE_LBA || mode == MODE_LA || mode == MODE_LA0 || mode == MODE_LBA2) {   // `level` = the tree stage
         const int chunk = dm.ls_chunk_t[level] > 0 ? dm.ls_chunk_t[level] : 1;
         g.grid_x = (ipow(d, level) + chunk - 1) / chunk;
         g.ls_chunk_k = chunk;
@@ -208,7 +210,7 @@ IlvGeo ilv_geometry(int mode, const Dims &dm, int level, int want_xi) {
     }
     // [exchange slots][maxima: waves x 3 x 64][64 live flags]; level kernels: the maxima reuse the exchange rows (spock_ilevel.hpp)
     const size_t red = (size_t)(g.threads / 64) * 3 * 64 * 8;
-    const bool lvk = (mode == MODE_LB || mode == MODE_LBA || mode == MODE_LA || mode == MODE_LA0);
+    const bool lvk = (mode == MODE_LB || mode == MODE_LBA || mode == MODE_LA || mode == MODE_LA0 || mode == MODE_LBA2);
     g.lds_bytes = (lvk ? ((size_t)g.ex_doubles * 8 > red ? (size_t)g.ex_doubles * 8 : red) : (size_t)g.ex_doubles * 8 + red) + 64 * 4 + 64;
     return g;
 }
@@ -436,6 +438,9 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
         dm.ls_chunk = 16;
         if (const char *e = std::getenv("SPOCK_AMD_ILV_CHUNK")) { dm.ls_chunk = std::atoi(e); if (dm.ls_chunk < 1) dm.ls_chunk = 1; }
         dm.n_bslots = dm.nsub;
+        // the two bottom stages in one launch (MODE_LBA2) when both are streamed; SPOCK_AMD_ILV_FUSE2=0: three launches (LB, LBA, LA)
+        dm.ilv_fuse2 = (dm.ilv_stream && N - 3 >= t0) ? 1 : 0;
+        if (const char *e = std::getenv("SPOCK_AMD_ILV_FUSE2")) { if (e[0] == '0') dm.ilv_fuse2 = 0; }
         if (dm.ilv_stream) {
             const long tiles = ((long)batch + 63) / 64;
             int slot = 0;
@@ -444,7 +449,16 @@ std::string host_build(const HostProblem &hp, int split_stage, BuildProducts &ou
                 if (c < 1) c = 1;
                 if (c > dm.ls_chunk) c = dm.ls_chunk;
                 dm.ls_chunk_t[t] = (int)c;
-                dm.ls_slot0[t] = slot; slot += (ipow(d, t) + (int)c - 1) / (int)c;
+                dm.ls_slot0[t] = slot;
+                if (dm.ilv_fuse2 && t == N - 3) {   // parents per workgroup: the chunk of the bottom stage counted in parents
+                    long cb = (long)ipow(d, N - 2) * tiles / 512;
+                    if (cb < 1) cb = 1;
+                    if (cb > dm.ls_chunk) cb = dm.ls_chunk;
+                    c = cb / d < 1 ? 1 : cb / d;
+                    dm.ls_chunk_t[t] = (int)c;
+                }
+                if (dm.ilv_fuse2 && t == N - 2) continue;   // its workgroups are those of stage N-3
+                slot += (ipow(d, t) + (int)c - 1) / (int)c;
             }
             dm.n_bslots = slot;
         }

@@ -57,6 +57,7 @@ struct LvRole {
     real dzx[P::MAXNX], dzu[P::MAXNU];                   // X: dz = zbar - z on them
     real nv7[P::MAXNX + P::MAXNU], dv7[P::MAXNX + P::MAXNU], lx7[P::MAXNX + P::MAXNU];   // X: vbar.v7, its dv and xi_2
     real vecy[P::MAXNY];                                 // R: the y part of (-gamma) L'vbar + zbar
+    real sown;                                           // R (LBA2): the node's own s entry of its parent's [y; s_ch; tau_ch]
 };
 template <class P>
 struct IState {

@@ -129,7 +129,7 @@ int launch_ilv_collect(real *const *z3, real *const *v2, const Ctl *ctl, long nz
 int launch_ilevel(int mode, const KArgs &a, void *stream);   // spock_lkernels.hip
 
 int launch_igroup(int mode, const KArgs &a, void *stream) {
-    if (mode == MODE_LB || mode == MODE_LBA || mode == MODE_LA || mode == MODE_LA0) return launch_ilevel(mode, a, stream);
+    if (mode == MODE_LB || mode == MODE_LBA || mode == MODE_LA || mode == MODE_LA0 || mode == MODE_LBA2) return launch_ilevel(mode, a, stream);
     hipStream_t st = (hipStream_t)stream;
     const Dims &dm = a.dm;
     const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;

@@ -20,6 +20,9 @@
 //   LA   (stages N-3 .. t0, bottom-up) backward step from c_i, e_i and the children's q (role AX); the [y; s_ch; tau_ch] half of the
 //                                      next phase A with S2 on (zbar, vbar) (role AR)
 //   LA0  (prologue, once per solve)    phase A + backward step of iteration 0 on (z, v), one wave per node (a_local_g)
+//   LBA2 (stage N-3, default)          LB of stage N-3, LBA of stage N-2 and LA of stage N-3 in ONE launch: a parent, then its children,
+//                                      then the parent's backward step; what the three launches handed to one another through HBM
+//                                      (x and q of the children, c_i / e_i, LA's re-reads) stays in registers / LDS
 // The arithmetic per entry is that of a_local_g / b_local_g / fwd_node / bwd_node (spock_device.hpp), block by block; sums over the
 // children that those accumulate into one register are formed here per role and added afterwards (a different, fixed order).
 // Reference: L! / L_transpose! / prox_f! / prox_h_conj! (implicit_l.jl:177-951), should_terminate! (cp.jl:54-123).
@@ -28,11 +31,12 @@
 
 namespace spock {
 
-// x_i (from zbar) and d_i of a node
+// x_i (from zbar; two-stage kernel LBA2: the children's x from the LDS rows `xs` their parent's role X filled) and d_i of a node
 template <class P, class ZB, class DB>
-SPK_DEV void lv_load_xd(const P &p, const Dims &dm, ZB zo, DB db, int node, real *xi, real *di) {
+SPK_DEV void lv_load_xd(const P &p, const Dims &dm, ZB zo, DB db, int node, real *xi, real *di, LVec xs = LVec{nullptr}) {
     const int nx = p.nx(), nu = p.nu();
-    SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = zo[dm.zx + node * nx + k];
+    if (xs) { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = xs[k]; }
+    else { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = zo[dm.zx + node * nx + k]; }
     SPK_UNROLL for (int k = 0; k < nu; ++k) di[k] = db[node * nu + k];
 }
 // u_i = K x_i + d_i  (fwd_node)
@@ -63,11 +67,11 @@ SPK_DEV void lv_child_x(const P &p, const Dims &dm, MatPtr SW, MatPtr Bm, int c,
 // ---- role X, in front of the barrier: forward step, box block v7 (implicit_l.jl:275-282, constraints.jl:38-54) ------------------
 template <class P, bool WX, class ZI, class VI, class ZB, class VO, class DB>
 SPK_DEV void lv_role_x(const P &p, const Dims &dm, MatPtr SW, MatPtr Bm, ZI z, VI v, ZB zo, VO vo, DB db, int node, bool store_children,
-                       const ProxScal &ps, real *mx, LvRole<P> &lr) {
+                       const ProxScal &ps, real *mx, LvRole<P> &lr, LVec xs = LVec{nullptr}, LVec xd = LVec{nullptr}) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu, i = node;
     const real sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg;
     real di[P::MAXNU];
-    lv_load_xd(p, dm, zo, db, i, lr.xi, di);
+    lv_load_xd(p, dm, zo, db, i, lr.xi, di, xs);
     real zx_[P::MAXNX], zu_[P::MAXNU], v7[P::MAXNX + P::MAXNU];
     SPK_UNROLL for (int k = 0; k < nx; ++k) zx_[k] = z[dm.zx + i * nx + k];
     SPK_UNROLL for (int k = 0; k < nu; ++k) zu_[k] = z[dm.zu + i * nu + k];
@@ -79,6 +83,7 @@ SPK_DEV void lv_role_x(const P &p, const Dims &dm, MatPtr SW, MatPtr Bm, ZI z, V
             real xc[P::MAXNX];
             lv_child_x(p, dm, SW, Bm, c, lr.xi, di, xc);
             SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + (i * d + 1 + c) * nx + k] = xc[k];
+            if (xd) { SPK_UNROLL for (int k = 0; k < nx; ++k) xd[c * nx + k] = xc[k]; }   // LBA2: handed to the children's roles through LDS
         }
     }
     SPK_UNROLL for (int k = 0; k < nxu; ++k) {
@@ -122,9 +127,11 @@ SPK_DEV void lv_finish_x_res(const P &p, const ProxScal &ps, LVec ex, int crow, 
 // C_c, then c_i / e_i (a_finish_ce).  Bottom stage (BOT): the backward step with the leaves' W_c q_c, V_c q_c from the roles L_c
 // (implicit_l.jl:584-637) -> q_i to cq, d_i to dbuf.  Other stages: c_i is parked in cq's row of the node and e_i in dbuf's (the
 // d_i of this iteration has been consumed in front of the barrier); LA turns them into q_i, d_i when the children's q exist.
-template <class P, bool BOT, class DB, class CQ>
+// DST (two-stage kernel LBA2): 1 = c_i, e_i to the LDS rows `qd` (the parent, whose backward step follows in the same workgroup),
+// 2 = q_i to the LDS rows `qd` instead of cq (a child: only its parent's backward step reads it)
+template <class P, bool BOT, int DST = 0, class DB, class CQ>
 SPK_DEV void lv_finish_x_next(const P &p, const Dims &dm, MatPtr M, const ProxScal &ps, LVec ex, int crow, int rL, int node, int stage,
-                              DB db, CQ cq, const LvRole<P> &lr) {
+                              DB db, CQ cq, const LvRole<P> &lr, LVec qd = LVec{nullptr}) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu;
     const real mg = -ps.gamma;
     real xbar[P::MAXNX], ubar[P::MAXNU];
@@ -143,8 +150,14 @@ SPK_DEV void lv_finish_x_next(const P &p, const Dims &dm, MatPtr M, const ProxSc
             SPK_UNROLL for (int r = 0; r < nu; ++r) s.ub[r] -= ex[base + nx + r];
         }
     }
+    if (DST == 1) {
+        SPK_UNROLL for (int k = 0; k < nx; ++k) qd[k] = s.xb[k];
+        SPK_UNROLL for (int k = 0; k < nu; ++k) qd[nx + k] = s.ub[k];
+        return;
+    }
     SPK_UNROLL for (int k = 0; k < nu; ++k) db[node * nu + k] = s.ub[k];
-    SPK_UNROLL for (int k = 0; k < nx; ++k) cq[node * nx + k] = s.xb[k];
+    if (DST == 2) { SPK_UNROLL for (int k = 0; k < nx; ++k) qd[k] = s.xb[k]; }
+    else { SPK_UNROLL for (int k = 0; k < nx; ++k) cq[node * nx + k] = s.xb[k]; }
 }
 
 // ---- role R: risk block v1, v2 of node i (implicit_l.jl:208-222, :833-851) --------------------------------------------------
@@ -222,6 +235,7 @@ SPK_DEV void lv_role_r(const P &p, const Dims &dm, MatPtr M, ZI z, VI v, ZB zb, 
     const real x1s = dv2 + nig * dzs;
     spk_resmax<IVec>(mx[0], x1s, mx[3]);
     if (WX) spk_resmax<IVec>(mx[2], x2 + x1s, mx[3]);
+    if (NEXTA) lr.sown = mgn * nv2 + zbs;   // this node's s entry of its PARENT's [y; s_ch; tau_ch] (lv_role_ar; used by LBA2 only)
 }
 
 // role R behind the barrier, bottom stage: S2 on [y_i; s_ch; tau_ch] (implicit_l.jl:708-726) -> the next zbar
@@ -244,12 +258,12 @@ SPK_DEV void lv_finish_r(const P &p, const Dims &dm, MatPtr M, LVec ex, int crow
 // `base` on: [L'dv (nxu)] [L'vbar (nxu)] [L'xi_2 (nxu), WX] [tau_j of the next phase A, TAU = bottom stage]
 template <class P, bool WX, bool TAU, class ZI, class VI, class ZB, class VO, class DB>
 SPK_DEV void lv_role_c(const P &p, const Dims &dm, MatPtr M, MatPtr SW, ZI z, VI v, ZB zb, VO vo, DB db, int node, int c, const ProxScal &ps,
-                       real *mx, LVec ex, int base) {
+                       real *mx, LVec ex, int base, LVec xs = LVec{nullptr}) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu, i = node;
     const real sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg, mgn = -ps.gamma;
     const int j = i * d + 1 + c, jn = j - 1;
     real xi[P::MAXNX], di[P::MAXNU], zx_[P::MAXNX], zu_[P::MAXNU];
-    lv_load_xd(p, dm, zb, db, i, xi, di);
+    lv_load_xd(p, dm, zb, db, i, xi, di, xs);
     SPK_UNROLL for (int k = 0; k < nx; ++k) zx_[k] = z[dm.zx + i * nx + k];
     SPK_UNROLL for (int k = 0; k < nu; ++k) zu_[k] = z[dm.zu + i * nu + k];
     real vin[P::MAXNX + P::MAXNU + 2];   // [v6, v3.., v4.., v5]: the ordering of the reference's workspace
@@ -323,14 +337,14 @@ SPK_DEV void lv_role_c(const P &p, const Dims &dm, MatPtr M, MatPtr SW, ZI z, VI
 // the parent's backward step: rows [W_c q_c | V_c q_c | s_c] of `ex` from rL on, q_c = -xbar_c (implicit_l.jl:578-582)
 template <class P, bool WX, class ZI, class VI, class ZB, class VO, class DB>
 SPK_DEV void lv_role_l(const P &p, const Dims &dm, MatPtr M, MatPtr SW, MatPtr Bm, ZI z, VI v, ZB zb, VO vo, DB db, int node, int c,
-                       const ProxScal &ps, real *mx, LVec ex, int rL) {
+                       const ProxScal &ps, real *mx, LVec ex, int rL, LVec xs = LVec{nullptr}) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), i = node;
     const real sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg, mgn = -ps.gamma;
     const int j = i * d + 1 + c, li = j - dm.nn;
     real xl[P::MAXNX];
     {
         real xi[P::MAXNX], di[P::MAXNU];
-        lv_load_xd(p, dm, zb, db, i, xi, di);
+        lv_load_xd(p, dm, zb, db, i, xi, di, xs);
         lv_child_x(p, dm, SW, Bm, c, xi, di, xl);
     }
     real zl[P::MAXNX], v11[P::MAXNX], v14[P::MAXNX];
@@ -504,9 +518,130 @@ SPK_DEV void ilevel_body(X &x, const KArgs &a, const real *zin_, const real *vin
         return;
     }
 
+    x.each([&](int tid, IState<P> &st) SPK_ILAMBDA { if (st.live) st.ps = make_ps(a.ctl[tile * 64 + (tid & 63)]); });
+    if (MODE == MODE_LBA2) {
+        // ---- the two bottom stages in one launch: `stage` = N-3.  Per parent: its LB step, the LBA step of each child, then its own
+        // backward step and S2 (what LA does) -- everything that flowed between the three launches through HBM stays in the workgroup:
+        //   x of the children       role X -> LDS rows `xrows` (and zbar, where it belongs)   instead of read back from zbar
+        //   c_i, e_i of the parent  role X -> LDS rows `cerows`                                instead of parked in cq / dbuf
+        //   q of the children       role X -> LDS rows `qrows`                                 instead of written to / read from cq
+        //   [y; s_ch; tau_ch]       role R -> LDS rows `vprows`, piece by piece               instead of LA's re-reads of zbar / vbar
+        // The parent's backward step and S2 run on the first two L_c waves -- idle during a parent's step -- behind the barrier of the
+        // NEXT parent's step (cerows / vprows are double-buffered over the parents), and once more after the last parent.
+        // The arithmetic per entry is that of LB / LBA / LA (the same functions), so the iterates are those of the three launches.
+        const MatPtr SWc = SW + dm.sw_stride;
+        const int ny = p.ny(), mrow = ny + 2 * d;
+        const int rows = lba_exchange_rows(nx, nu, d, WX);
+        const int crow = (2 + (WX ? 1 : 0)) * nxu + 1, oX = 2 * nxu, rL = d * crow;
+        real *const xrows = x.lds() + 2L * rows * 64, *const qrows = xrows + (long)d * nx * 64;
+        real *const cerows = qrows + (long)d * nx * 64, *const vprows = cerows + 2L * nxu * 64;
+        // backward step (implicit_l.jl:584-637) and S2 (implicit_l.jl:708-726) of parent `node` from the LDS rows of parity `par`
+        auto parent_tail = [&](int tid, int which, int node, int par) SPK_ILAMBDA {
+            if (which == 0) {
+                const IVec db = vw(dbuf, n_db, tid), cqv = vw(cq, n_cq, tid);
+                const LVec ce = LVec{cerows + (long)par * nxu * 64 + (tid & 63)};
+                TState<P> s;
+                s.node = node; s.c0 = node * d + 1; s.stage = stage; s.lvl = 0; s.pos = 0; s.kids_leaf = false; s.kids_gleaf = true; s.active = true;
+                SPK_UNROLL for (int k = 0; k < nx; ++k) s.xb[k] = ce[k];
+                SPK_UNROLL for (int k = 0; k < nu; ++k) s.ub[k] = ce[nx + k];
+                bwd_node(p, dm, SW, 0, LVec{nullptr}, LVec{qrows + (tid & 63)}, cqv + (long)node * nx, s);
+                SPK_UNROLL for (int k = 0; k < nu; ++k) db[node * nu + k] = s.dd[k];
+            } else {
+                const LVec vp = LVec{vprows + (long)par * mrow * 64 + (tid & 63)};
+                real vec[P::MAXM];
+                SPK_UNROLL for (int k = 0; k < mrow; ++k) vec[k] = vp[k];
+                TState<P> s;
+                s.node = node; s.c0 = node * d + 1;
+                a_finish_s2(p, dm, M, vw(znext, dm.nz, tid), s, vec);
+            }
+        };
+        int step = 0;
+        for (int pos = lo; pos < hi; ++pos) {
+            const int node = first + pos, par = (pos - lo) & 1;
+            {
+                const int buf = step & 1;
+                ++step;
+                x.phased([&](int tid, IState<P> &st, bool pre, bool post) SPK_ILAMBDA {
+                    if (!st.live) return;
+                    const int role = spk_uniform(tid >> 6);
+                    const ProxScal &ps = st.ps;
+                    const IVec z = vw(zin, dm.nz, tid), v = vw(vin, dm.nv, tid), zo = vw(zout, dm.nz, tid), vo = vw(vout, dm.nv, tid);
+                    const IVec db = vw(dbuf, n_db, tid);
+                    const LVec ex = LVec{x.lds() + (long)buf * rows * 64 + (tid & 63)};
+                    if (role == 0) {
+                        if (pre) lv_role_x<P, WX>(p, dm, SW, Bm, z, v, zo, vo, db, node, true, ps, st.mx, st.lr, LVec{nullptr}, LVec{xrows + (tid & 63)});
+                        x.sync();
+                        if (post) {
+                            lv_finish_x_res<P, WX>(p, ps, ex, crow, oX, st.mx, st.lr);
+                            lv_finish_x_next<P, false, 1>(p, dm, M, ps, ex, crow, rL, node, stage, db, db, st.lr,
+                                                          LVec{cerows + (long)par * nxu * 64 + (tid & 63)});
+                        }
+                    } else if (role == 1) {
+                        if (pre) lv_role_r<P, WX, true>(p, dm, M, z, v, zo, vo, node, ps, st.mx, st.lr);
+                        x.sync();
+                        if (post) {
+                            const LVec vp = LVec{vprows + (long)par * mrow * 64 + (tid & 63)};
+                            SPK_UNROLL for (int k = 0; k < ny; ++k) vp[k] = st.lr.vecy[k];
+                            SPK_UNROLL for (int c = 0; c < d; ++c) vp[ny + d + c] = ex[c * crow + crow - 1];
+                        }
+                    } else if (role < 2 + d) {
+                        if (pre) lv_role_c<P, WX, true>(p, dm, M, SW, z, v, zo, vo, db, node, role - 2, ps, st.mx, ex, (role - 2) * crow);
+                        x.sync();
+                    } else {
+                        x.sync();
+                        if (post && pos > lo && role < 4 + d) parent_tail(tid, role - 2 - d, node - 1, par ^ 1);
+                    }
+                });
+            }
+            for (int c = 0; c < d; ++c) {
+                const int child = node * d + 1 + c, buf = step & 1;
+                ++step;
+                x.phased([&](int tid, IState<P> &st, bool pre, bool post) SPK_ILAMBDA {
+                    if (!st.live) return;
+                    const int role = spk_uniform(tid >> 6);
+                    const ProxScal &ps = st.ps;
+                    const IVec z = vw(zin, dm.nz, tid), v = vw(vin, dm.nv, tid), zo = vw(zout, dm.nz, tid), vo = vw(vout, dm.nv, tid);
+                    const IVec db = vw(dbuf, n_db, tid);
+                    const LVec ex = LVec{x.lds() + (long)buf * rows * 64 + (tid & 63)};
+                    const LVec xs = LVec{xrows + (long)c * nx * 64 + (tid & 63)};
+                    if (role == 0) {
+                        if (pre) lv_role_x<P, WX>(p, dm, SWc, Bm, z, v, zo, vo, db, child, false, ps, st.mx, st.lr, xs);
+                        x.sync();
+                        if (post) {
+                            lv_finish_x_res<P, WX>(p, ps, ex, crow, oX, st.mx, st.lr);
+                            lv_finish_x_next<P, true, 2>(p, dm, M, ps, ex, crow, rL, child, stage + 1, db, db, st.lr,
+                                                         LVec{qrows + (long)c * nx * 64 + (tid & 63)});
+                        }
+                    } else if (role == 1) {
+                        if (pre) lv_role_r<P, WX, true>(p, dm, M, z, v, zo, vo, child, ps, st.mx, st.lr);
+                        x.sync();
+                        if (post) {
+                            lv_finish_r(p, dm, M, ex, crow, rL, child, vw(znext, dm.nz, tid), st.lr);
+                            const LVec vp = LVec{vprows + (long)par * mrow * 64 + (tid & 63)};
+                            vp[ny + c] = st.lr.sown;
+                        }
+                    } else if (role < 2 + d) {
+                        if (pre) lv_role_c<P, WX, true>(p, dm, M, SWc, z, v, zo, vo, db, child, role - 2, ps, st.mx, ex, (role - 2) * crow, xs);
+                        x.sync();
+                    } else {
+                        if (pre) lv_role_l<P, WX>(p, dm, M, SWc, Bm, z, v, zo, vo, db, child, role - 2 - d, ps, st.mx, ex, rL, xs);
+                        x.sync();
+                    }
+                });
+            }
+        }
+        if (hi > lo) {   // the last parent's backward step and S2
+            x.barrier();
+            x.each([&](int tid, IState<P> &st) SPK_ILAMBDA {
+                if (!st.live) return;
+                const int role = spk_uniform(tid >> 6);
+                if (role >= 2 + d && role < 4 + d) parent_tail(tid, role - 2 - d, first + hi - 1, (hi - 1 - lo) & 1);
+            });
+        }
+    }
+
     // ---- LB / LBA: one wave per role, one node at a time, one barrier per node ---------------------------------------------
     constexpr bool BOT = (MODE == MODE_LBA);
-    x.each([&](int tid, IState<P> &st) SPK_ILAMBDA { if (st.live) st.ps = make_ps(a.ctl[tile * 64 + (tid & 63)]); });
     const int rows = BOT ? lba_exchange_rows(nx, nu, d, WX) : lb_exchange_rows(nx, nu, d, WX);
     // rows of one exchange buffer: per child c a block of `crow` rows from role C_c, [L'dv | L'vbar | L'xi_2 (LOG mode) |
     // tau_j (bottom)], then -- bottom -- per child [W_c q_c | V_c q_c | s_c] from role L_c
@@ -514,7 +649,7 @@ SPK_DEV void ilevel_body(X &x, const KArgs &a, const real *zin_, const real *vin
     // Every role is ONE branch that contains its part in front of the barrier, the barrier and its finishing part: what a role
     // carries across the barrier (LvRole) is then live in that role's branch only.  (x.phased: the GPU policy runs the body once
     // with pre = post = true and sync() = the workgroup barrier; the host emulation runs it per thread with pre, then with post.)
-    for (int pos = lo; pos < hi; ++pos) {
+    for (int pos = lo; pos < hi && MODE != MODE_LBA2; ++pos) {
         const int node = first + pos, buf = (pos - lo) & 1;
         x.phased([&](int tid, IState<P> &st, bool pre, bool post) SPK_ILAMBDA {
             if (!st.live) return;

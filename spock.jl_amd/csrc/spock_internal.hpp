@@ -53,6 +53,7 @@ struct Dims {
     // element-major regime, level-streaming kernels (spock_ilevel.hpp) for the stages t0 .. N-2: one launch per tree stage, a
     // workgroup works on ls_chunk consecutive nodes of the stage and owns one slot of residual partials
     int ilv_stream;              // 1: stages >= t0 run as level kernels (LB / LBA / LA) instead of the bottom-group kernels
+    int ilv_fuse2;               // 1: stages N-3 and N-2 run as ONE launch (MODE_LBA2); ls_chunk_t[N-3] = parents per workgroup, its slots cover both
     int ls_chunk;                // nodes of a stage per workgroup: upper bound (wide stages)
     int ls_chunk_t[kMaxStages];  // ... per stage: narrow stages take fewer nodes per workgroup so that the launch still fills the chip
     int ls_slot0[kMaxStages];    // first partial slot of every streamed stage
@@ -218,7 +219,10 @@ enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, 
                  MODE_FLAT_B = 17,     // phase B of every non-leaf node on the zbar the sweeps completed; residual maxima per workgroup
                  MODE_FLAT_B_SP = 18,  // ... plus the SP driver's inner products (KArgs::sp_mode)
                  MODE_FLAT_BA = 19,    // phase B of iteration k and phase A of iteration k + 1 on the iterate just produced, one launch
-                 N_ALL_MODES = 20 };
+                 // element-major regime: the two bottom stages in one launch (spock_ilevel.hpp), grp_level = N-3: LB of stage N-3, LBA of stage
+                 // N-2 and LA of stage N-3 per parent -- what the three launches hand to one another stays in registers / LDS
+                 MODE_LBA2 = 20,
+                 N_ALL_MODES = 21 };
 
 // ---- host build step (spock_host.cpp) -------------------------------------------------------------
 struct HostProblem {

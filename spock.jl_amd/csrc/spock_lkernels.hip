@@ -54,13 +54,14 @@ static int launch_lvariant(int mode, const KArgs &a_in, hipStream_t st) {
     const size_t lds = g.lds_bytes;
     if (lds > 160 * 1024) return (int)hipErrorInvalidConfiguration;
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the exchange rows of the wider shapes): raise it once per kernel and device
-        static bool raised_dev[16][4][2] = {};
+        static bool raised_dev[16][5][2] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
         bool always = false;
-        bool &raised_flag = dev >= 0 ? raised_dev[dev][mode - MODE_LB][a.want_xi ? 1 : 0] : always;
+        bool &raised_flag = dev >= 0 ? raised_dev[dev][mode == MODE_LBA2 ? 4 : mode - MODE_LB][a.want_xi ? 1 : 0] : always;
         if (!raised_flag) {
             const void *fn = mode == MODE_LB ? (a.want_xi ? (const void *)spock_ilevel_kernel<P, MODE_LB, true> : (const void *)spock_ilevel_kernel<P, MODE_LB, false>)
+                           : mode == MODE_LBA2 ? (a.want_xi ? (const void *)spock_ilevel_kernel<P, MODE_LBA2, true> : (const void *)spock_ilevel_kernel<P, MODE_LBA2, false>)
                            : mode == MODE_LBA ? (a.want_xi ? (const void *)spock_ilevel_kernel<P, MODE_LBA, true> : (const void *)spock_ilevel_kernel<P, MODE_LBA, false>)
                            : mode == MODE_LA ? (const void *)spock_ilevel_kernel<P, MODE_LA, false> : (const void *)spock_ilevel_kernel<P, MODE_LA0, false>;
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -78,6 +79,10 @@ static int launch_lvariant(int mode, const KArgs &a_in, hipStream_t st) {
         case MODE_LBA:
             if (a.want_xi) hipLaunchKernelGGL((spock_ilevel_kernel<P, MODE_LBA, true>), grid, block, lds, st, a, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next);
             else hipLaunchKernelGGL((spock_ilevel_kernel<P, MODE_LBA, false>), grid, block, lds, st, a, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next);
+            break;
+        case MODE_LBA2:
+            if (a.want_xi) hipLaunchKernelGGL((spock_ilevel_kernel<P, MODE_LBA2, true>), grid, block, lds, st, a, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next);
+            else hipLaunchKernelGGL((spock_ilevel_kernel<P, MODE_LBA2, false>), grid, block, lds, st, a, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next);
             break;
         case MODE_LA: hipLaunchKernelGGL((spock_ilevel_kernel<P, MODE_LA, false>), grid, block, lds, st, a, cn, cn, a.z_out, a.v_out, a.z_next); break;
         case MODE_LA0: hipLaunchKernelGGL((spock_ilevel_kernel<P, MODE_LA0, false>), grid, block, lds, st, a, a.z_in, a.v_in, a.z_out, dn, dn); break;

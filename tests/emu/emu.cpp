@@ -214,6 +214,7 @@ static int launch_ivariant(int mode, const KArgs &a_in) {
         case MODE_FINALIZE: run_iblocks<P, MODE_FINALIZE>(a, g.grid_x, g.threads); break;
         case MODE_LB: if (a.want_xi) run_lblocks<P, MODE_LB, true>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, nullptr); else run_lblocks<P, MODE_LB>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, nullptr); break;
         case MODE_LBA: if (a.want_xi) run_lblocks<P, MODE_LBA, true>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next); else run_lblocks<P, MODE_LBA>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next); break;
+        case MODE_LBA2: if (a.want_xi) run_lblocks<P, MODE_LBA2, true>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next); else run_lblocks<P, MODE_LBA2>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, a.v_out, a.z_next); break;
         case MODE_LA: run_lblocks<P, MODE_LA>(a, g.grid_x, g.threads, nullptr, nullptr, a.z_out, a.v_out, a.z_next); break;
         case MODE_LA0: run_lblocks<P, MODE_LA0>(a, g.grid_x, g.threads, a.z_in, a.v_in, a.z_out, nullptr, nullptr); break;
         default: return 1;

@@ -752,13 +752,50 @@ def test_emulated_profile_sequence_lists_the_launches_of_an_iteration(S, emu):
     S.solve_model(m, x0, tol=0.0)
     t0 = m.sizes.split_stage
     seq = m.profile_sequence(2)
-    assert [(n, lv) for n, lv, _ in seq] == [("crown", 0)] + [("lb", t) for t in range(t0, 6)] + [("lba", 6)] + [("la", t) for t in range(5, t0 - 1, -1)]
+    # (default: the two bottom stages 5 and 6 as one launch, LBA2; SPOCK_AMD_ILV_FUSE2=0: lb .. 5, lba 6, la 5 ..)
+    assert [(n, lv) for n, lv, _ in seq] == [("crown", 0)] + [("lb", t) for t in range(t0, 5)] + [("lba2", 5)] + [("la", t) for t in range(4, t0 - 1, -1)]
     assert all(ms >= 0.0 for _, _, ms in seq)
     z14 = m.solver_state.z.copy()
     ref = S.build_model(*specs, lib_path=emu, batch=3, layout="interleaved", max_iter=14)
     S.solve_model(ref, x0, tol=0.0)
     assert relerr(z14, ref.solver_state.z) <= 1e-12
     m.close(); ref.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"SPOCK_EMU_REVERSE": "1"}, {"SPOCK_EMU_REVERSE_BLOCKS": "1"}, {"SPOCK_AMD_ILV_CHUNK": "3"}])
+def test_emulated_two_bottom_stages_in_one_launch(S, O, emu, monkeypatch, env):
+    """LBA2 (spock_ilevel.hpp): LB of stage N-3, LBA of stage N-2 and LA of stage N-3 as one launch -- x and q of the children,
+    c_i / e_i and the parent's [y; s_ch; tau_ch] stay in LDS rows / registers.  Same functions, same order per entry: the iterates
+    must be BITWISE those of the three-launch sequence (SPOCK_AMD_ILV_FUSE2=0), in either thread / workgroup order, with chunks
+    that leave a ragged last workgroup, for d = 2 and d = 3, SILENT and LOG mode (the L'xi_2 rows), and match the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cases = [(S.get_server_heat_specs(8, 5, 2, nu=2), {"split_stage": 2}, 70), (S.get_server_heat_specs(6, 5, 2), {"split_stage": 3}, 3),
+             (S.get_random_linear_specs(5, 3, 2, d=3), {"split_stage": 2}, 3)]
+    for specs, kw, B in cases:
+        flat = S.flatten_problem(*specs)
+        x0 = 0.1 * (1 + 0.05 * np.arange(B))[:, None] * np.cos(np.arange(flat.nx))[None, :]
+        out = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("SPOCK_AMD_ILV_FUSE2", fuse)
+            m = S.build_model(*specs, lib_path=emu, batch=B, layout="interleaved", max_iter=30, **kw)
+            names = [n for n, _, _ in m.profile_sequence(1)]
+            assert ("lba2" in names) == (fuse == "1") and ("lba" in names) == (fuse == "0")
+            m.reset()
+            res = []
+            for verbose in (S.SILENT, S.LOG):
+                m.reset()
+                rs = S.solve_model(m, x0, tol=1e-6, verbose=verbose)
+                res.append((m.solver_state.z.copy(), m.solver_state.v.copy(), [r["iterations"] for r in rs], m.history(0)["xi1"].copy()))
+            out[fuse] = res
+            if fuse == "1":
+                for b in (0, B - 1):
+                    o = O.Oracle(flat, O.CP); ro = o.solve(x0[b], tol=1e-6, max_iter=30, verbose=O.LOG)
+                    assert rs[b]["iterations"] == ro["iterations"]
+                    assert relerr(m.solver_state.z.reshape(B, -1)[b], o.z) <= 1e-9 and relerr(m.solver_state.v.reshape(B, -1)[b], o.v) <= 1e-9
+            m.close()
+        for (z1, v1, it1, h1), (z0, v0, it0, h0) in zip(out["1"], out["0"]):
+            assert it1 == it0 and np.array_equal(z1, z0) and np.array_equal(v1, v0) and np.array_equal(h1, h0)
 
 
 def test_emulated_interleaved_equals_instance_major_and_mpc(S, O, emu):
