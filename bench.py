@@ -18,7 +18,7 @@ inputs are resident in HBM before the timed region (a step uploads only the nx-d
     value = n_gpus * batch * iters * steps / time      ("Spock iterations per second", whole job, weak scaling)
 
 The JSON line also carries
-  roofline        the dominant kernel (the bottom-stage level kernel LBA): `bytes_per_launch` = the entry-by-entry count of what that
+  roofline        the dominant kernel (LBA2: the level kernel of the two bottom stages N-3 and N-2): `bytes_per_launch` = the entry-by-entry count of what that
                   kernel must move (`bytes_model` says which count), `avg_launch_ms` its average HIP-event duration measured live
                   after the timed region on the stream the kernels run on, `achieved` / `frac` = that rate against the 8 TB/s HBM peak;
                   `traffic` (`traffic_raw`) = PMC bytes of the same kernel per launch from the committed rocprofv3 passes of the SAME
@@ -123,6 +123,21 @@ def lba_necessary_bytes(flat):
     writes = (2 * nxu + nu) + (2 * ny + 1 + 2 * d) + d * (nxu + 2) + d * (3 * nx + 2)
     n_bottom = flat.nl // d
     return W * n_bottom * (reads + writes)
+
+
+def lba2_necessary_bytes(flat):
+    """The two bottom stages as one launch, LBA2 (spock_ilevel.hpp), per instance and launch, entry by entry (W = 8).  The nodes of
+    stage N-2 as in lba_necessary_bytes minus what now stays in LDS (their x_i is not read back, their q_i not written); per node of
+    stage N-3 (children = non-leaf nodes):
+    reads   X: x_i, d_i, z.x_i, z.u_i, v7 | R: zbar.y, z.y, zbar.s_i, z.s_i, v1, v2 | C_c: zbar.tau, z.tau, v3..v6
+    writes  X: u_i, x of the children, vbar.v7, d_i, q_i | R: vbar.v1, v2, next zbar's y, s_ch, tau_ch | C_c: vbar.v3..v6"""
+    W, nx, nu, ny, d = 8, flat.nx, flat.nu, flat.ny, flat.d
+    nxu = nx + nu
+    reads = 3 * nxu + (3 * ny + 3) + d * (nxu + 4)
+    writes = (nu + d * nx + nxu + nu + nx) + (2 * ny + 1 + 2 * d) + d * (nxu + 2)
+    n_bottom = flat.nl // d
+    n_parent = n_bottom // d
+    return lba_necessary_bytes(flat) - W * n_bottom * 2 * nx + W * n_parent * (reads + writes)
 
 
 def block_relerr(flat, which, a, b):
@@ -302,13 +317,18 @@ def main(argv=None):
         model_txt = "necessary bytes of the fused kernel (reads z, v, zbar's s/tau/y, d; writes zbar, vbar, d)" if nec else "SURVEY 8d"
         kernel_txt = f"spock {'element-major ' if ilv else ''}group kernel, mode {kname}"
         seq = model.profile_sequence(24) if ilv else []
-        lba = [(n, lv, ms) for (n, lv, ms) in seq if n == "lba"]
-        if lba:   # level-streaming kernels: the dominant kernel is the bottom stage's LBA; its own necessary bytes
+        lba = [(n, lv, ms) for (n, lv, ms) in seq if n in ("lba", "lba2")]
+        if lba:   # level-streaming kernels: the dominant kernel is the bottom kernel -- LBA2 (stages N-3 and N-2 in one launch) or LBA
             dom_ms = lba[0][2]
-            bytes_used = B * lba_necessary_bytes(flat)
-            model_txt = "necessary bytes of the bottom-stage kernel LBA (bench.py: lba_necessary_bytes)"
-            kernel_txt = "spock_ilevel_kernel, mode LBA (bottom stage: forward step + phase B + next phase A + backward step)"
-            k = pmc_kernels.get("lba")
+            if lba[0][0] == "lba2":
+                bytes_used = B * lba2_necessary_bytes(flat)
+                model_txt = "necessary bytes of the two-bottom-stages kernel LBA2 (bench.py: lba2_necessary_bytes)"
+                kernel_txt = "spock_ilevel_kernel, mode LBA2 (stages N-3 and N-2 in one launch: forward step + phase B + next phase A + backward step)"
+            else:
+                bytes_used = B * lba_necessary_bytes(flat)
+                model_txt = "necessary bytes of the bottom-stage kernel LBA (bench.py: lba_necessary_bytes)"
+                kernel_txt = "spock_ilevel_kernel, mode LBA (bottom stage: forward step + phase B + next phase A + backward step)"
+            k = pmc_kernels.get(lba[0][0])
             traffic = k["hbm_bytes_per_launch_corrected"] if k else None
             traffic_raw = k.get("hbm_bytes_per_launch_raw") if k else None
         ach = bytes_used / (dom_ms * 1e-3) / 1e9

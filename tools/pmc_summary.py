@@ -26,7 +26,7 @@ MODES = {"1": "sub_a", "2": "crown", "3": "sub_b", "5": "sub_ba", "0": "full"}
 IMODES = {"1": "sub_a", "2": "crown_top", "5": "sub_ba", "9": "crown_a", "10": "crown_up", "11": "crown_down", "4": "finalize"}
 
 
-LMODES = {"12": "lb", "13": "lba", "14": "la", "15": "la0"}   # level-streaming kernels (spock_ilevel.hpp)
+LMODES = {"12": "lb", "13": "lba", "14": "la", "15": "la0", "20": "lba2"}   # level-streaming kernels (spock_ilevel.hpp)
 
 
 def kind(name):
@@ -73,9 +73,9 @@ for k, e in out["kernels"].items():
     f, w = e.get("FETCH_SIZE_KB_mean", 0.0), e.get("WRITE_SIZE_KB_mean", 0.0)
     e["hbm_bytes_per_launch_raw"] = int((f + w) * 1024)
     e["hbm_bytes_per_launch_corrected"] = int((2 * f + w) * 1024)
-# ---- one iteration: every kind that is launched at least once per iteration of the bottom kernel (lba, or sub_ba / sub_b / full)
+# ---- one iteration: every kind that is launched at least once per iteration of the bottom kernel (lba2 / lba, or sub_ba / sub_b / full)
 ks = out["kernels"]
-bottom = next((k for k in ("lba", "sub_ba", "sub_b", "full") if k in ks), None)
+bottom = next((k for k in ("lba2", "lba", "sub_ba", "sub_b", "full") if k in ks), None)
 dur = {}   # mean duration per kind from the --stats pass (ns -> ms), pooled over the kernel names of a kind
 if os.path.exists(stats_csv):
     tot, cnt = {}, {}
