@@ -11,8 +11,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["spock_kernels.hip", "spock_fkernels.hip", "spock_skernels.hip", "spock_ikernels.hip", "spock_lkernels.hip", "spock_bkernels.hip", "spock_abi.cpp", "spock_host.cpp", "spock_rt_hip.cpp"]
-HEADERS = ["spock_flat_local.hpp", "spock_gpu_exec.hpp", "spock_device.hpp", "spock_group.hpp", "spock_igroup.hpp", "spock_ilevel.hpp", "spock_build.hpp", "spock_shapes.hpp", "spock_internal.hpp", "spock_rt.hpp", "spock_sp.hpp", "spock_team_local.hpp", os.path.join("..", "..", "include", "spock_amd.h")]
+SOURCES = ["spock_kernels.hip", "spock_fkernels.hip", "spock_skernels.hip", "spock_ikernels.hip", "spock_lkernels.hip", "spock_rkernels.hip", "spock_bkernels.hip", "spock_abi.cpp", "spock_host.cpp", "spock_rt_hip.cpp"]
+HEADERS = ["spock_flat_local.hpp", "spock_gpu_exec.hpp", "spock_device.hpp", "spock_group.hpp", "spock_igroup.hpp", "spock_ilevel.hpp", "spock_rgroup.hpp", "spock_build.hpp", "spock_shapes.hpp", "spock_internal.hpp", "spock_rt.hpp", "spock_sp.hpp", "spock_team_local.hpp", os.path.join("..", "..", "include", "spock_amd.h")]
 _API = os.path.join("..", "..", "include", "spock_amd.h")
 DEPS = {   # headers each translation unit includes
     "spock_skernels.hip": ["spock_gpu_exec.hpp", "spock_device.hpp", "spock_internal.hpp"],
@@ -20,6 +20,7 @@ DEPS = {   # headers each translation unit includes
     "spock_kernels.hip": ["spock_gpu_exec.hpp", "spock_device.hpp", "spock_group.hpp", "spock_team_local.hpp", "spock_sp.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
     "spock_ikernels.hip": ["spock_device.hpp", "spock_igroup.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
     "spock_lkernels.hip": ["spock_device.hpp", "spock_igroup.hpp", "spock_ilevel.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
+    "spock_rkernels.hip": ["spock_device.hpp", "spock_igroup.hpp", "spock_ilevel.hpp", "spock_rgroup.hpp", "spock_internal.hpp", "spock_shapes.hpp"],
     "spock_bkernels.hip": ["spock_device.hpp", "spock_build.hpp", "spock_internal.hpp"],
     "spock_abi.cpp": ["spock_internal.hpp", "spock_rt.hpp", _API],
     "spock_host.cpp": ["spock_internal.hpp"],

@@ -41,6 +41,7 @@ struct spock_handle_s {
     // device memory
     real *d_mats = nullptr, *d_z[3] = {nullptr, nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}, *d_v2x = nullptr;
     bool lat_regime = false;   // few workgroups in flight (register-resident sweep): SUB_B runs as MODE_SUB_B_LAT
+    bool rlane = false;        // ... and the fused iteration's SUB_BA as the role-lane kernel MODE_SUB_BA_R (spock_rgroup.hpp)
     bool dyn_on_device = false;   // spock_update_dynamics has run: P, K, Rtilde^-1, ABK of spock_get_build_product come from the device pool
     int sp_variant = 0, sp_max_bt = 8;   // SP: 0 = the reference's run_sp! as it stands, 1 = corrected Anderson + working line search
     bool sp_fused = false;   // SP: the inner products with the residuals come out of phase B instead of out of LOP kernels
@@ -157,6 +158,7 @@ KArgs make_args(spock_handle_s *h, bool op, int parity, unsigned flags) {
         a.z_next = h->i_z[(parity + 2) % 3];
         a.ilv = 1; a.bp = h->bpad; a.cq = h->i_cq; a.want_xi = h->want_xi;
     }
+    if (!op && h->rlane) a.want_xi = h->want_xi;
     a.xlbuf = h->d_xlbuf;
     a.flat_local = (!op && h->flat_local) ? 1 : 0; a.flat_chunks = h->flat_chunks;
     a.parity = parity;
@@ -213,7 +215,7 @@ int launch_cp_iteration(spock_handle_s *h, int k, unsigned flags = 0, void *stre
     }
     if (!h->fused) e = launch_group(MODE_SUB_A, a, stream);
     if (e == 0) e = launch_group(MODE_CROWN, a, stream);
-    if (e == 0) e = launch_group(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), a, stream);
+    if (e == 0) e = launch_group(h->fused ? (h->rlane ? MODE_SUB_BA_R : MODE_SUB_BA) : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), a, stream);
     return e;
 }
 // G iterations of every instance.  Element-major regime with several tile groups: fork from the handle's stream, one chain of G
@@ -289,6 +291,9 @@ int choose_cp_sequence(spock_handle_s *h) {
         return 0;
     }
     h->fused = dm.t0 > 0 && (dm.nx + dm.nu <= 8);
+    // (the role-lane kernel MODE_SUB_BA_R, which replaces SUB_BA when few workgroups are in flight, does not have SUB_BA's register
+    // problem: with it the fused sequence also serves the larger compile-time shapes, e.g. nx = nu = 5)
+    if (!h->fused && h->mats_stride == 0 && rlane_applies(dm, h->batch, true)) h->fused = true;
     if (std::getenv("SPOCK_AMD_NO_FUSE")) { h->fused = false; return 0; }
     if (const char *e = std::getenv("SPOCK_AMD_FUSE")) {
         if (e[0] == 't') return time_cp_sequences(h);
@@ -462,7 +467,6 @@ int sp_init_state(spock_handle_s *h) {
     SpCtl c;
     std::memset(&c, 0, sizeof(c));
     c.R[0] = c.R[4] = c.R[8] = 1.;
-    c.crho[0] = c.crho[1] = c.crho[2] = 1.;
     c.r_safe = INFINITY;
     h->h_sp.assign(B, c);
     if (!e) e = rt::h2d(h->s_ctl, h->h_sp.data(), B * sizeof(SpCtl), h->stream);
@@ -819,6 +823,7 @@ int spock_create(const spock_problem_t *p, const spock_options_t *o, spock_handl
     for (auto &c : h->h_ctl) c.done = 1;
     if ((e = rt::h2d(h->d_ctl, h->h_ctl.data(), B * sizeof(Ctl), h->stream))) return bail(e, "upload");
     if (alg == SPOCK_ALG_CP && (e = choose_cp_sequence(h))) return bail(e, "timing the CP kernel sequences");
+    h->rlane = alg == SPOCK_ALG_CP && !h->ilv && !h->flat_local && h->mats_stride == 0 && rlane_applies(dm, h->batch, h->fused);
     if (alg == SPOCK_ALG_SP) h->sp_fused = !std::getenv("SPOCK_AMD_SP_LOP");
     if (alg == SPOCK_ALG_SP && (e = sp_init_state(h))) return bail(e, "SP state initialisation");
     if ((e = rt::sync(h->stream))) return bail(e, "hipStreamSynchronize");
@@ -952,7 +957,7 @@ static int solve_impl(spock_handle_t h, const double *x0, double tol, int32_t ve
 
     const int G = h->graph_iters > 0 ? h->graph_iters : -h->graph_iters;   // negative: eager launches
     const bool use_graph = h->graph_iters > 0 && rt::graphs_supported();
-    h->want_xi = (h->ilv && verbose == SPOCK_LOG) ? 1 : 0;
+    h->want_xi = ((h->ilv || h->rlane) && verbose == SPOCK_LOG) ? 1 : 0;   // (kernel variants with the combined residual: another graph)
     void *&graph = h->want_xi ? h->graph_log : h->graph;
     if (use_graph && !graph) {
         RTCHECK(rt::capture_begin(h->stream));
@@ -1297,7 +1302,7 @@ static int profile_impl(spock_handle_t h, int32_t reps, double *avg_ms, int32_t 
             for (int t = pdm.t0; t <= t_lb; ++t) push(MODE_LB, it, t);
             if (pdm.ilv_fuse2) push(MODE_LBA2, it, pdm.N - 3); else push(MODE_LBA, it, pdm.N - 2);
             for (int t = t_lb; t >= pdm.t0; --t) push(MODE_LA, it, t);
-        } else push(h->fused ? MODE_SUB_BA : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), it);
+        } else push(h->fused ? (h->rlane ? MODE_SUB_BA_R : MODE_SUB_BA) : (h->lat_regime ? MODE_SUB_B_LAT : MODE_SUB_B), it);
     }
     std::vector<void *> ev(seq.size() * 2, nullptr);
     for (auto &e : ev) RTCHECK(rt::event_create(&e));

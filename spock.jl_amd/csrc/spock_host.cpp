@@ -215,6 +215,21 @@ IlvGeo ilv_geometry(int mode, const Dims &dm, int level, int want_xi) {
     return g;
 }
 
+// Role-lane subtree kernel (spock_rgroup.hpp) in place of MODE_SUB_BA: the fused iteration of a compile-time shape with shared costs,
+// groups of at most 64 non-leaf nodes (lane = node) and so few workgroups in flight that a node-local phase is one thread's latency
+// rather than the chip's throughput (measured crossover: see DESIGN.md).  SPOCK_AMD_RLANE=0 / 1 overrides the batch rule.
+bool rlane_applies(const Dims &dm, int batch, bool fused) {
+    const char *e = std::getenv("SPOCK_AMD_RLANE");
+    if (e && e[0] == '0') return false;
+    if (!fused || dm.t0 <= 0) return false;
+    if (!have_static_variant(dm.nx, dm.nu, dm.d, dm.ny)) return false;
+    if (!(dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1)) return false;
+    if (group_threads(dm.d, dm.sub_stages) > 64 || group_threads(dm.d, dm.t0 + 1) > 64) return false;
+    if ((long)rgroup_lds_doubles(dm.nx, dm.nu, dm.d, true) * 8 + 64 > 64 * 1024) return false;
+    if (e && e[0] == '1') return true;
+    return (long)batch * (dm.nsub + 1) <= 256;
+}
+
 bool team_local_applies(const Dims &dm) {
     if (std::getenv("SPOCK_AMD_NO_TEAM_LOCAL")) return false;
     const bool big = (dm.nx > 8 || dm.nu > 8) || std::getenv("SPOCK_AMD_FORCE_TEAM_LOCAL");   // (the override is for experiments)

@@ -67,17 +67,23 @@ SPK_DEV void lv_child_x(const P &p, const Dims &dm, MatPtr SW, MatPtr Bm, int c,
 // ---- role X, in front of the barrier: forward step, box block v7 (implicit_l.jl:275-282, constraints.jl:38-54) ------------------
 template <class P, bool WX, class ZI, class VI, class ZB, class VO, class DB>
 SPK_DEV void lv_role_x(const P &p, const Dims &dm, MatPtr SW, MatPtr Bm, ZI z, VI v, ZB zo, VO vo, DB db, int node, bool store_children,
-                       const ProxScal &ps, real *mx, LvRole<P> &lr, LVec xs = LVec{nullptr}, LVec xd = LVec{nullptr}) {
+                       const ProxScal &ps, real *mx, LvRole<P> &lr, LVec xs = LVec{nullptr}, LVec xd = LVec{nullptr}, LVec gu = LVec{nullptr}) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu, i = node;
     const real sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg;
     real di[P::MAXNU];
-    lv_load_xd(p, dm, zo, db, i, lr.xi, di, xs);
+    // (gu: x_i AND u_i are given -- the forward sweep of the role-lane subtree kernel, spock_rgroup.hpp, has produced and stored them)
+    if (gu) {
+        SPK_UNROLL for (int k = 0; k < nx; ++k) lr.xi[k] = xs[k];
+        SPK_UNROLL for (int k = 0; k < nu; ++k) { lr.ui[k] = gu[k]; di[k] = 0.; }
+    } else lv_load_xd(p, dm, zo, db, i, lr.xi, di, xs);
     real zx_[P::MAXNX], zu_[P::MAXNU], v7[P::MAXNX + P::MAXNU];
     SPK_UNROLL for (int k = 0; k < nx; ++k) zx_[k] = z[dm.zx + i * nx + k];
     SPK_UNROLL for (int k = 0; k < nu; ++k) zu_[k] = z[dm.zu + i * nu + k];
     SPK_UNROLL for (int k = 0; k < nxu; ++k) v7[k] = v[dm.o7 + i * nxu + k];
-    lv_u_of(p, dm, SW, lr.xi, di, lr.ui);
-    SPK_UNROLL for (int k = 0; k < nu; ++k) zo[dm.zu + i * nu + k] = lr.ui[k];
+    if (!gu) {
+        lv_u_of(p, dm, SW, lr.xi, di, lr.ui);
+        SPK_UNROLL for (int k = 0; k < nu; ++k) zo[dm.zu + i * nu + k] = lr.ui[k];
+    }
     if (store_children) {
         SPK_UNROLL for (int c = 0; c < d; ++c) {
             real xc[P::MAXNX];
@@ -258,12 +264,13 @@ SPK_DEV void lv_finish_r(const P &p, const Dims &dm, MatPtr M, LVec ex, int crow
 // `base` on: [L'dv (nxu)] [L'vbar (nxu)] [L'xi_2 (nxu), WX] [tau_j of the next phase A, TAU = bottom stage]
 template <class P, bool WX, bool TAU, class ZI, class VI, class ZB, class VO, class DB>
 SPK_DEV void lv_role_c(const P &p, const Dims &dm, MatPtr M, MatPtr SW, ZI z, VI v, ZB zb, VO vo, DB db, int node, int c, const ProxScal &ps,
-                       real *mx, LVec ex, int base, LVec xs = LVec{nullptr}) {
+                       real *mx, LVec ex, int base, LVec xs = LVec{nullptr}, LVec gu = LVec{nullptr}) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), nxu = nx + nu, i = node;
     const real sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg, mgn = -ps.gamma;
     const int j = i * d + 1 + c, jn = j - 1;
     real xi[P::MAXNX], di[P::MAXNU], zx_[P::MAXNX], zu_[P::MAXNU];
-    lv_load_xd(p, dm, zb, db, i, xi, di, xs);
+    if (gu) { SPK_UNROLL for (int k = 0; k < nx; ++k) xi[k] = xs[k]; }
+    else lv_load_xd(p, dm, zb, db, i, xi, di, xs);
     SPK_UNROLL for (int k = 0; k < nx; ++k) zx_[k] = z[dm.zx + i * nx + k];
     SPK_UNROLL for (int k = 0; k < nu; ++k) zu_[k] = z[dm.zu + i * nu + k];
     real vin[P::MAXNX + P::MAXNU + 2];   // [v6, v3.., v4.., v5]: the ordering of the reference's workspace
@@ -275,7 +282,8 @@ SPK_DEV void lv_role_c(const P &p, const Dims &dm, MatPtr M, MatPtr SW, ZI z, VI
     real wxv[P::MAXNX], dzx[P::MAXNX], wuv[P::MAXNU], dzu[P::MAXNU];
     {
         real ui[P::MAXNU];
-        lv_u_of(p, dm, SW, xi, di, ui);
+        if (gu) { SPK_UNROLL for (int k = 0; k < nu; ++k) ui[k] = gu[k]; }
+        else lv_u_of(p, dm, SW, xi, di, ui);
         SPK_UNROLL for (int k = 0; k < nx; ++k) { wxv[k] = 2. * xi[k] + -1. * zx_[k]; dzx[k] = xi[k] - zx_[k]; }
         SPK_UNROLL for (int k = 0; k < nu; ++k) { wuv[k] = 2. * ui[k] + -1. * zu_[k]; dzu[k] = ui[k] - zu_[k]; }
     }
@@ -337,12 +345,14 @@ SPK_DEV void lv_role_c(const P &p, const Dims &dm, MatPtr M, MatPtr SW, ZI z, VI
 // the parent's backward step: rows [W_c q_c | V_c q_c | s_c] of `ex` from rL on, q_c = -xbar_c (implicit_l.jl:578-582)
 template <class P, bool WX, class ZI, class VI, class ZB, class VO, class DB>
 SPK_DEV void lv_role_l(const P &p, const Dims &dm, MatPtr M, MatPtr SW, MatPtr Bm, ZI z, VI v, ZB zb, VO vo, DB db, int node, int c,
-                       const ProxScal &ps, real *mx, LVec ex, int rL, LVec xs = LVec{nullptr}) {
+                       const ProxScal &ps, real *mx, LVec ex, int rL, LVec xs = LVec{nullptr}, LVec gxl = LVec{nullptr}) {
     const int nx = p.nx(), nu = p.nu(), d = p.d(), i = node;
     const real sg = ps.sigma, isg = ps.inv_sigma, nis = ps.inv_sigma_neg, nig = ps.inv_gamma_neg, mgn = -ps.gamma;
     const int j = i * d + 1 + c, li = j - dm.nn;
     real xl[P::MAXNX];
-    {
+    if (gxl) {   // the leaf's x is given (and stored) by the forward sweep of the role-lane subtree kernel
+        SPK_UNROLL for (int k = 0; k < nx; ++k) xl[k] = gxl[k];
+    } else {
         real xi[P::MAXNX], di[P::MAXNU];
         lv_load_xd(p, dm, zb, db, i, xi, di, xs);
         lv_child_x(p, dm, SW, Bm, c, xi, di, xl);
@@ -350,7 +360,7 @@ SPK_DEV void lv_role_l(const P &p, const Dims &dm, MatPtr M, MatPtr SW, MatPtr B
     real zl[P::MAXNX], v11[P::MAXNX], v14[P::MAXNX];
     SPK_UNROLL for (int k = 0; k < nx; ++k) { zl[k] = z[dm.zx + j * nx + k]; v11[k] = v[dm.o11 + li * nx + k]; v14[k] = v[dm.o14 + li * nx + k]; }
     const real zbs = zb[dm.zs + j], zs_ = z[dm.zs + j], v12 = v[dm.o12 + li], v13 = v[dm.o13 + li];
-    SPK_UNROLL for (int k = 0; k < nx; ++k) zb[dm.zx + j * nx + k] = xl[k];
+    if (!gxl) { SPK_UNROLL for (int k = 0; k < nx; ++k) zb[dm.zx + j * nx + k] = xl[k]; }
     const MatPtr SN = M + dm.mSqQN + (P::SHARED ? 0 : li) * nx * nx;
     real wl[P::MAXNX], dl[P::MAXNX];
     SPK_UNROLL for (int k = 0; k < nx; ++k) { wl[k] = 2. * xl[k] + -1. * zl[k]; dl[k] = xl[k] - zl[k]; }

@@ -153,8 +153,6 @@ struct SpCtl {          // per instance, device memory; survives between solves 
     double r_safe, rnorm, rtilde, rho_dot, coef;
     double r2, r3, rho, g[3];
     double xi_fb[2];    // residuals of the plain CP step z <- T(z) (the fall-back), kept from the first T evaluation
-    double crho[3];     // norm of each PHYSICAL column of Q: the columns are stored unnormalised and divided where they are read
-                        // (spock_sp.hpp: FLAT1 / FLAT2), so that FLAT3 neither reads nor rewrites the newest one; 1 initially
 };
 
 constexpr int kSpSums = 10;   // partial sums per workgroup of the flat / LOP kernels
@@ -224,7 +222,9 @@ enum GroupMode { MODE_FULL = 0, MODE_SUB_A = 1, MODE_CROWN = 2, MODE_SUB_B = 3, 
                  // element-major regime: the two bottom stages in one launch (spock_ilevel.hpp), grp_level = N-3: LB of stage N-3, LBA of stage
                  // N-2 and LA of stage N-3 per parent -- what the three launches hand to one another stays in registers / LDS
                  MODE_LBA2 = 20,
-                 N_ALL_MODES = 21 };
+                 // single-instance regime: MODE_SUB_BA with the node-local phases split over role lanes (spock_rgroup.hpp): wave = role, lane = node
+                 MODE_SUB_BA_R = 21,
+                 N_ALL_MODES = 22 };
 
 // ---- host build step (spock_host.cpp) -------------------------------------------------------------
 struct HostProblem {
@@ -272,11 +272,15 @@ int ilevel_waves(int mode, const Dims &dm);
 constexpr int lba_exchange_rows(int nx, int nu, int d, bool wx) { return d * ((wx ? 3 : 2) * (nx + nu) + 1) + d * (nx + nu + 1); }
 constexpr int lb_exchange_rows(int nx, int nu, int d, bool wx) { return d * (wx ? 3 : 2) * (nx + nu); }
 int ilevel_ex_doubles(int mode, const Dims &dm, int want_xi);
+// role-lane subtree kernel (spock_rgroup.hpp), LDS doubles: [sweep exchange 64 nx][given rows (nx + nu + d nx) 64][role exchange rows 64][s entries 64]
+constexpr int rgroup_lds_doubles(int nx, int nu, int d, bool wx) { return 64 * nx + (nx + nu + d * nx) * 64 + lba_exchange_rows(nx, nu, d, wx) * 64 + 64; }
 
 // ---- kernel launchers (spock_kernels.hip) ---------------------------------------------------------
 // Each returns a hipError_t cast to int.  `stream` is a hipStream_t.
 int launch_group(int mode, const KArgs &a, void *stream);
 int launch_igroup(int mode, const KArgs &a, void *stream);   // element-major batched regime (a.ilv), spock_ikernels.hip
+int launch_rgroup(const KArgs &a, void *stream);             // MODE_SUB_BA_R (spock_rkernels.hip)
+bool rlane_applies(const Dims &dm, int batch, bool fused);   // the handle runs MODE_SUB_BA_R in place of MODE_SUB_BA
 bool have_static_variant(int nx, int nu, int d, int ny);
 // closed-loop step of examples/server_heat/mpc_simulation.jl:164-177 on the device
 struct MpcArgs {

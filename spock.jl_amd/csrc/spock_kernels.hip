@@ -113,6 +113,7 @@ int launch_group(int mode, const KArgs &a, void *stream) {
     const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
     static const bool force_dyn = std::getenv("SPOCK_AMD_FORCE_DYN") != nullptr;   // experiments: run-time-dimension kernels for every shape
     if (a.ilv) return launch_igroup(mode, a, stream);   // element-major batched regime (spock_ikernels.hip)
+    if (mode == MODE_SUB_BA_R) return launch_rgroup(a, stream);   // role-lane subtree kernel (spock_rkernels.hip)
     if (mode >= MODE_FLAT_A && mode <= MODE_FLAT_BA) return launch_flat_local(mode, a, stream);   // spock_fkernels.hip
     if (a.flat_local && cm == 2 && (mode == MODE_SUB_A || mode == MODE_CROWN || mode == MODE_SUB_B) && sweep_kernels_apply(dm))
         return launch_sweep(mode, a, stream);                                                      // spock_skernels.hip

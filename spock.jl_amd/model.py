@@ -214,7 +214,7 @@ class Model:
         return st.tolist()
 
     MODE_NAMES = {0: "full", 1: "sub_a", 2: "crown", 3: "sub_b", 5: "sub_ba", 8: "sub_b_lat", 9: "crown_a", 10: "i_up", 11: "i_down",
-                  12: "lb", 13: "lba", 14: "la", 15: "la0", 20: "lba2", 16: "flat_a", 17: "flat_b", 18: "flat_b_sp", 19: "flat_ba"}
+                  12: "lb", 13: "lba", 14: "la", 15: "la0", 20: "lba2", 21: "sub_ba_r", 16: "flat_a", 17: "flat_b", 18: "flat_b_sp", 19: "flat_ba"}
 
     def profile_sequence(self, reps: int = 20):
         """Average HIP-event duration (ms) of every launch of one CP iteration, in launch order: [(kernel, level, avg_ms)]."""

@@ -18,6 +18,7 @@
 #include "../../spock.jl_amd/csrc/spock_flat_local.hpp"
 #include "../../spock.jl_amd/csrc/spock_igroup.hpp"
 #include "../../spock.jl_amd/csrc/spock_ilevel.hpp"
+#include "../../spock.jl_amd/csrc/spock_rgroup.hpp"
 #include "../../spock.jl_amd/csrc/spock_build.hpp"
 #include "../../spock.jl_amd/csrc/spock_sp.hpp"
 #include "../../spock.jl_amd/csrc/spock_team_local.hpp"
@@ -263,9 +264,69 @@ bool have_static_variant(int nx, int nu, int d, int ny) {
     return false;
 }
 
+// ---- role-lane subtree kernel (spock_rgroup.hpp), emulated: threads one after the other between barriers, role step in two phases
+template <class P>
+struct EmuRExec {
+    std::vector<RState<P>> st;
+    std::vector<real> ex;
+    std::vector<std::array<real, 3>> m;
+    int nthreads_v;
+    bool reverse;
+    real r3[3] = {0., 0., 0.};
+    EmuRExec(int thr, int ex_doubles) : st(thr), ex((size_t)ex_doubles + 8, 0.), m(thr), nthreads_v(thr), reverse(env_on("SPOCK_EMU_REVERSE")) {}
+    template <class F>
+    void each(F &&f) {
+        if (!reverse) for (int t = 0; t < nthreads_v; ++t) f(t, st[t]);
+        else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t]);
+    }
+    void barrier() {}
+    template <class F>
+    void phased(F &&f) {
+        for (int ph = 0; ph < 2; ++ph) {
+            if (!reverse) for (int t = 0; t < nthreads_v; ++t) f(t, st[t], ph == 0, ph == 1);
+            else for (int t = nthreads_v - 1; t >= 0; --t) f(t, st[t], ph == 0, ph == 1);
+        }
+    }
+    void sync() {}
+    real *lds() { return ex.data(); }
+    int nthreads() const { return nthreads_v; }
+    void stash3(int tid, const real *mx) { m[tid] = {mx[0], mx[1], mx[2]}; }
+    void reduce3() {
+        for (int k = 0; k < 3; ++k) r3[k] = 0.;
+        for (int t = 0; t < nthreads_v; ++t) for (int k = 0; k < 3; ++k) r3[k] = spk_max_nan(r3[k], m[t][k]);
+    }
+    real red3(int k) const { return r3[k]; }
+};
+template <class P>
+static int launch_rvariant(const KArgs &a_in) {
+    KArgs a = a_in;
+    const Dims &dm = a.dm;
+    a.ex_doubles = rgroup_lds_doubles(dm.nx, dm.nu, dm.d, a.want_xi != 0);
+    const bool rev = env_on("SPOCK_EMU_REVERSE_BLOCKS");
+    const int gx = dm.nsub + 1, thr = 64 * (2 + 2 * dm.d);
+    for (int inst = 0; inst < a.batch; ++inst)
+        for (int gi = 0; gi < gx; ++gi) {
+            const int g = rev ? gx - 1 - gi : gi;
+            EmuRExec<P> x(thr, a.ex_doubles);
+            if (a.want_xi) rgroup_body<P, true>(x, a, inst, g); else rgroup_body<P, false>(x, a, inst, g);
+        }
+    return 0;
+}
+int launch_rgroup(const KArgs &a, void *) {
+    const Dims &dm = a.dm;
+    const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
+#define X(a_, b_, c_, e_)                                                                  \
+    if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                            \
+        return cm == 2 ? launch_rvariant<StaticDims<a_, b_, c_, e_, 2>>(a) : cm == 1 ? launch_rvariant<StaticDims<a_, b_, c_, e_, 1>>(a) : 9;
+    SPOCK_STATIC_SHAPES(X)
+#undef X
+    return 9;
+}
+
 int launch_group(int mode, const KArgs &a, void *) {
     const Dims &dm = a.dm;
     const int cm = (dm.nQ == 1 && dm.nR == 1 && dm.nQN == 1) ? (dm.diag_costs ? 2 : 1) : 0;
+    if (mode == MODE_SUB_BA_R) return launch_rgroup(a, nullptr);
     if (a.ilv) {
 #define X(a_, b_, c_, e_)                                                                  \
     if (dm.nx == a_ && dm.nu == b_ && dm.d == c_ && dm.ny == e_)                            \

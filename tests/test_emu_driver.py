@@ -762,6 +762,46 @@ def test_emulated_profile_sequence_lists_the_launches_of_an_iteration(S, emu):
     m.close(); ref.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"SPOCK_EMU_REVERSE": "1"}, {"SPOCK_EMU_REVERSE_BLOCKS": "1"}])
+def test_emulated_role_lane_subtree_kernel(S, O, emu, monkeypatch, env):
+    """MODE_SUB_BA_R (spock_rgroup.hpp): the fused iteration's subtree kernel with the node-local phases split over role lanes (wave =
+    role, lane = node) -- chosen for compile-time shapes with few workgroups in flight.  Against the oracle (SILENT and LOG mode: the
+    kernel variant with the combined residual), in both thread / workgroup orders, several splits (subtrees of one to five levels, a
+    one-node crown), d = 2 and d = 3, two instances; equal to rounding to MODE_SUB_BA (SPOCK_AMD_RLANE=0), whose sums over the children
+    run in another order."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cases = [(S.get_server_heat_specs(7, 5, 2, nu=2), s) for s in (1, 3, 5)] + [(S.get_server_heat_specs(6, 5, 2), 2), (S.get_random_linear_specs(5, 3, 2, d=3), 2),
+                                                                                (S.get_random_linear_specs(7, 2, 1), 3)]
+    for specs, split in cases:
+        flat = S.flatten_problem(*specs)
+        x0 = np.stack([0.1 * np.cos(np.arange(flat.nx)), 0.13 * np.ones(flat.nx)])
+        out = {}
+        for rl in ("1", "0"):
+            monkeypatch.setenv("SPOCK_AMD_RLANE", rl)
+            m = S.build_model(*specs, lib_path=emu, graph_iters=-6, split_stage=split, batch=2, max_iter=60)
+            names = [n for n, _, _ in m.profile_sequence(1)]
+            # (SPOCK_AMD_RLANE=0: SUB_BA for nx + nu <= 8, the plain three-kernel sequence for the larger shapes)
+            assert names == ["crown", "sub_ba_r"] if rl == "1" else names in (["crown", "sub_ba"], ["sub_a", "crown", "sub_b_lat"], ["sub_a", "crown", "sub_b"]), names
+            res = []
+            for verbose, ov in ((S.SILENT, O.SILENT), (S.LOG, O.LOG)):
+                m.reset()
+                rs = S.solve_model(m, x0, tol=1e-5, verbose=verbose)
+                res.append((m.solver_state.z.copy(), m.solver_state.v.copy(), [r["iterations"] for r in rs]))
+                if rl == "1":
+                    for b in range(2):
+                        o = O.Oracle(flat, O.CP); ro = o.solve(x0[b], tol=1e-5, max_iter=60, verbose=ov, history=70)
+                        assert (rs[b]["iterations"], rs[b]["status"]) == (ro["iterations"], ro["status"])
+                        assert relerr(m.solver_state.z[b], o.z) <= 1e-9 and relerr(m.solver_state.v[b], o.v) <= 1e-9
+                        if verbose == S.LOG:
+                            h = m.history(b)
+                            assert np.max(np.abs(h["xi"] - ro["hist_xi"]) / ro["hist_xi"]) <= 1e-8
+            out[rl] = res
+            m.close()
+        for (z1, v1, it1), (z0, v0, it0) in zip(out["1"], out["0"]):
+            assert it1 == it0 and relerr(z1, z0) <= 1e-11 and relerr(v1, v0) <= 1e-11
+
+
 @pytest.mark.parametrize("env", [{}, {"SPOCK_EMU_REVERSE": "1"}, {"SPOCK_EMU_REVERSE_BLOCKS": "1"}, {"SPOCK_AMD_ILV_CHUNK": "3"}])
 def test_emulated_two_bottom_stages_in_one_launch(S, O, emu, monkeypatch, env):
     """LBA2 (spock_ilevel.hpp): LB of stage N-3, LBA of stage N-2 and LA of stage N-3 as one launch -- x and q of the children,
