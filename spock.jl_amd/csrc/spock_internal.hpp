@@ -272,8 +272,12 @@ int ilevel_waves(int mode, const Dims &dm);
 constexpr int lba_exchange_rows(int nx, int nu, int d, bool wx) { return d * ((wx ? 3 : 2) * (nx + nu) + 1) + d * (nx + nu + 1); }
 constexpr int lb_exchange_rows(int nx, int nu, int d, bool wx) { return d * (wx ? 3 : 2) * (nx + nu); }
 int ilevel_ex_doubles(int mode, const Dims &dm, int want_xi);
-// role-lane subtree kernel (spock_rgroup.hpp), LDS doubles: [sweep exchange 64 nx][given rows (nx + nu + d nx) 64][role exchange rows 64][s entries 64]
-constexpr int rgroup_lds_doubles(int nx, int nu, int d, bool wx) { return 64 * nx + (nx + nu + d * nx) * 64 + lba_exchange_rows(nx, nu, d, wx) * 64 + 64; }
+// role-lane subtree kernel (spock_rgroup.hpp), LDS doubles: [sweep vectors XQ 64 nx | ED 64 nu | UL 64 nu | XL 64 d nx][given rows (nx + nu + d nx) 64]
+// [role exchange rows 64][s entries 64]; threads per workgroup: one wave per role, and T = 8 lanes per node for the lane-team sweeps
+constexpr int rgroup_lds_doubles(int nx, int nu, int d, bool wx) {
+    return 64 * nx + 2 * 64 * nu + 64 * d * nx + (nx + nu + d * nx) * 64 + lba_exchange_rows(nx, nu, d, wx) * 64 + 64;
+}
+constexpr int kRgroupThreads = 512;
 
 // ---- kernel launchers (spock_kernels.hip) ---------------------------------------------------------
 // Each returns a hipError_t cast to int.  `stream` is a hipStream_t.

@@ -7,14 +7,15 @@
 // instructions on one SIMD while the other three idle.  The element-major kernels already split a node over ROLES X / R / C_c / L_c
 // (spock_ilevel.hpp) that exchange a few partial results through LDS rows; here the same role functions run with lane = NODE (the
 // <= 64 non-leaf nodes of the group) and wave = role, on the plain instance-major vectors:
-//   1. forward sweep, one thread per node (fwd_node; wave 0), x_i / u_i / x_leaf -> zbar
-//   2. wave 0 hands x_i, u_i, x_leaf to the role lanes through LDS rows (the roles' "given" mode: nothing is recomputed)
+//   1. forward sweep: the register-resident lane-team sweep (fwd_team_reg: T = 8 lanes per node, rows in registers), x_i / u_i /
+//      x_leaf -> zbar
+//   2. ... and transposed into LDS rows, one column per node, for the role lanes (the roles' "given" mode: nothing is recomputed)
 //   3. ONE role step for all nodes of the group at once: X (box block v7, residuals, next phase A on (x_i, u_i) -> c_i, e_i; at the
 //      bottom level also the backward step with the leaves' terms -> q_i, d_i), R (risk block; bottom: S2), C_c (cone block of child c),
 //      L_c (leaf child c) -- LBA's roles for the bottom level, LB's for the levels above, chosen per lane
 //   4. S2 of the other levels: [y; s_ch; tau_ch] with the children's s entries from their R lanes through LDS (children in other
 //      workgroups -- the crown's extra workgroup, last level: recomputed, risk_v2_only, as MODE_SUB_BA does)
-//   5. backward sweep over the levels above the bottom one, one thread per node (bwd_node); q_root -> qroot, d_i -> dbuf
+//   5. backward sweep over the levels above the bottom one (bwd_team_reg); q_root -> qroot, d_i -> dbuf
 // The crown's extra workgroup (g == nsub) runs 2-4 on the nodes above the split stage and leaves c_i, e_i in cbuf for MODE_CROWN.
 // Interfaces (dbuf, qroot, cbuf, zbar's y / s / tau, the third z buffer) are those of MODE_SUB_BA: the kernels are interchangeable
 // launch by launch.  Sums over the children are formed per role and added in child order (as in the element-major kernels): the
@@ -53,9 +54,26 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
     double *partials = a.partials + (long)inst * n_groups * kPartialStride;
     const int rows = lba_exchange_rows(nx, nu, d, WX);
     const int crow = (2 + (WX ? 1 : 0)) * nxu + 1, oX = 2 * nxu, rL = d * crow;
-    real *const exs = x.lds(), *const G = exs + 64 * nx, *const exr = G + (long)(nxu + d * nx) * 64, *const sown = exr + (long)rows * 64;
+    // LDS: [sweep vectors XQ 64 nx | ED 64 nu | UL 64 nu | XL 64 d nx][given rows (nx + nu + d nx) 64][role exchange rows 64][s entries 64]
+    TeamLds tl;
+    tl.XQ = x.lds(); tl.ED = tl.XQ + 64 * nx; tl.UL = tl.ED + 64 * nu; tl.XL = tl.UL + 64 * nu;
+    real *const G = tl.XL + 64 * d * nx, *const exr = G + (long)(nxu + d * nx) * 64, *const sown = exr + (long)rows * 64;
+    const int T = 8, nthr = x.nthreads();   // register-resident lane-team sweep (bwd_team_reg / fwd_team_reg): T lanes per node, T * nodes <= threads
+    auto level_geo = [&](int l, int &lfirst, int &cnt, long &gfirst) SPK_ILAMBDA {
+        cnt = 1; lfirst = 0;
+        for (int k = 0; k < l; ++k) { lfirst += cnt; cnt *= d; }
+        gfirst = dm.first[root_stage + l] + (long)root_pos * cnt;
+    };
     const MatPtr Bm = M + dm.mB, SWb = M + dm.mSweep + (long)(dm.N - 2) * dm.sw_stride;   // (W, V of the bottom stage: role L_c)
 
+    // (debug: wall-clock stamps of workgroup 0 at the phase boundaries, SPOCK_AMD_DEBUG_FLAGS & F_DBG_STAMPS; tools/explore_stamps.py)
+    int stamp_idx = 0;
+    auto stamp = [&]() SPK_ILAMBDA {
+        if ((a.flags & F_DBG_STAMPS) && a.dbg && inst == 0 && g == 0 && stamp_idx < 64)
+            x.each([&](int tid, RState<P> &) SPK_ILAMBDA { if (tid == 0) x.clocks(a.dbg + 2 * 128 + 2 * stamp_idx); });
+        ++stamp_idx;
+    };
+    stamp();   // 0: entry
     x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
         init_geometry(p, dm, tid & 63, root_stage, root_pos, stages, crown_blk, st.s);
         st.mx[0] = st.mx[1] = st.mx[2] = st.mx[3] = 0.;
@@ -65,45 +83,53 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
         st.ps = ps;
     });
 
-    // ---- 1. x_i, u_i (and the leaves' x) of the group's nodes
+    // ---- 1. x_i, u_i (and the leaves' x) of the group's nodes -> LDS vectors (and zbar); 2. the role lanes' given rows
     if (!crown_blk) {
         const int root_node = dm.first[root_stage] + root_pos;
         const real *xroot = zo + dm.zx + (long)root_node * nx;
         x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
-            TState<P> &s = st.s;
-            if (tid < 64 && s.active) { SPK_UNROLL for (int k = 0; k < nu; ++k) s.dd[k] = db[s.node * nu + k]; }
+            team_reg_init(p, dm, M, root_stage, stages, T, tid, st.s, 2);   // this thread's rows of ABK, B, K
+            if (tid < nx) tl.XQ[tid] = xroot[tid];
+            for (int l = 0; l <= stages - 2; ++l) {
+                int lfirst, cnt; long gfirst;
+                level_geo(l, lfirst, cnt, gfirst);
+                for (int k = tid; k < cnt * nu; k += nthr) tl.ED[lfirst * nu + k] = db[gfirst * nu + k];
+            }
         });
+        x.barrier();
+        stamp();   // 1: d_i, x_root in LDS
         for (int l = 0; l <= stages - 2; ++l) {
-            const MatPtr SW = M + dm.mSweep + (long)(root_stage + l) * dm.sw_stride;
-            x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
-                if (tid < 64 && st.s.active && st.s.lvl == l) fwd_node(p, dm, SW, Bm, tid, exs, xroot, st.s);
-            });
+            x.each([&](int, RState<P> &st) SPK_ILAMBDA { if (st.s.tn_li >= 0 && st.s.tn_lvl == l) fwd_team_reg(p, stages, tl, st.s); });
             x.barrier();
         }
-        x.each([&](int tid, RState<P> &st) SPK_ILAMBDA { if (tid < 64 && st.s.active) fwd_store(p, dm, zo, st.s); });
-    } else {
-        x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
-            TState<P> &s = st.s;
-            if (tid < 64 && s.active) {
-                SPK_UNROLL for (int k = 0; k < nx; ++k) s.xb[k] = zo[dm.zx + (long)s.node * nx + k];
-                SPK_UNROLL for (int k = 0; k < nu; ++k) s.ub[k] = zo[dm.zu + (long)s.node * nu + k];
+        stamp();   // 2: forward sweep
+        // x_i, u_i, x_leaf: coalesced level chunks -> zbar, and transposed into the given rows [x_i | u_i | x_leaf c], one column per node
+        x.each([&](int tid, RState<P> &) SPK_ILAMBDA {
+            for (int l = 0; l <= stages - 2; ++l) {
+                int lfirst, cnt; long gfirst;
+                level_geo(l, lfirst, cnt, gfirst);
+                for (int k = tid; k < cnt * nx; k += nthr) zo[dm.zx + gfirst * nx + k] = tl.XQ[lfirst * nx + k];
+                for (int k = tid; k < cnt * nu; k += nthr) zo[dm.zu + gfirst * nu + k] = tl.UL[lfirst * nu + k];
+            }
+            int lfirst, cnt; long gfirst;
+            level_geo(stages - 2, lfirst, cnt, gfirst);
+            const long gl_first = dm.first[root_stage + stages - 1] + (long)root_pos * cnt * d;
+            for (int k = tid; k < cnt * d * nx; k += nthr) zo[dm.zx + gl_first * nx + k] = tl.XL[k];
+            for (int k = tid; k < nl_grp * nx; k += nthr) { const int li = k / nx, e = k - li * nx; G[e * 64 + li] = tl.XQ[k]; }
+            for (int k = tid; k < nl_grp * nu; k += nthr) { const int li = k / nu, e = k - li * nu; G[(nx + e) * 64 + li] = tl.UL[k]; }
+            for (int k = tid; k < cnt * d * nx; k += nthr) {   // leaf (pos d + c) entry e -> row nxu + c nx + e of its parent's column
+                const int lf = k / nx, e = k - lf * nx, pos = lf / d, c = lf - pos * d;
+                G[(nxu + c * nx + e) * 64 + lfirst + pos] = tl.XL[k];
             }
         });
+    } else {
+        x.each([&](int tid, RState<P> &) SPK_ILAMBDA {   // the crown's nodes are the global nodes 0 .. nl_grp - 1
+            for (int k = tid; k < nl_grp * nx; k += nthr) { const int li = k / nx, e = k - li * nx; G[e * 64 + li] = zo[dm.zx + k]; }
+            for (int k = tid; k < nl_grp * nu; k += nthr) { const int li = k / nu, e = k - li * nu; G[(nx + e) * 64 + li] = zo[dm.zu + k]; }
+        });
     }
-    // ---- 2. hand them to the role lanes: rows [x_i | u_i | x_leaf of child 0 .. d-1], one column per node
-    x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
-        TState<P> &s = st.s;
-        if (tid >= 64 || !s.active) return;
-        const LVec gv = LVec{G + tid};
-        SPK_UNROLL for (int k = 0; k < nx; ++k) gv[k] = s.xb[k];
-        SPK_UNROLL for (int k = 0; k < nu; ++k) gv[nx + k] = s.ub[k];
-        if (s.kids_leaf) {
-            SPK_UNROLL for (int c = 0; c < d; ++c) {
-                SPK_UNROLL for (int k = 0; k < nx; ++k) gv[nxu + c * nx + k] = s.xl[c][k];
-            }
-        }
-    });
     x.barrier();
+    stamp();   // 3: zbar stored, x / u handed to the role lanes
     // ---- 3. the role step: wave = role, lane = node
     x.phased([&](int tid, RState<P> &st, bool pre, bool post) SPK_ILAMBDA {
         TState<P> &s = st.s;
@@ -120,8 +146,8 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
                 // c_i, e_i (bottom level: q_i, d_i with the leaves' terms) through the node's own given rows into the sweep thread's state
                 if (bot) lv_finish_x_next<P, true, 1>(p, dm, M, ps, ex, crow, rL, node, s.stage, db, db, st.lr, gv);
                 else lv_finish_x_next<P, false, 1>(p, dm, M, ps, ex, crow, rL, node, s.stage, db, db, st.lr, gv);
-                SPK_UNROLL for (int k = 0; k < nx; ++k) s.xb[k] = gv[k];
-                SPK_UNROLL for (int k = 0; k < nu; ++k) s.ub[k] = gv[nx + k];
+                SPK_UNROLL for (int k = 0; k < nx; ++k) tl.XQ[lane * nx + k] = gv[k];
+                SPK_UNROLL for (int k = 0; k < nu; ++k) tl.ED[lane * nu + k] = gv[nx + k];
             }
         } else if (role == 1) {
             if (act && pre) lv_role_r<P, WX, true>(p, dm, M, z, v, zo, vo, node, ps, st.mx, st.lr);
@@ -138,13 +164,14 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
             if (act && pre) lv_role_c<P, WX, true>(p, dm, M, SWb, z, v, zo, vo, (const real *)db, node, role - 2, ps, st.mx, ex, (role - 2) * crow, gv, gv + nx);
             x.sync();
         } else {
-            if (act && bot && pre)
+            if (role < 2 + 2 * d && act && bot && pre)   // (the waves past the last role only take part in the sweeps)
                 lv_role_l<P, WX>(p, dm, M, SWb, Bm, z, v, zo, vo, (const real *)db, node, role - 2 - d, ps, st.mx, ex, rL, LVec{nullptr},
                                  gv + (nxu + (role - 2 - d) * nx));
             x.sync();
         }
     });
     x.barrier();
+    stamp();   // 4: role step
     // ---- 4. S2 of the levels above the bottom one (implicit_l.jl:708-726)
     x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
         TState<P> &s = st.s;
@@ -160,37 +187,32 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
         }
         a_finish_s2(p, dm, M, zn, s, st.vecp);
     });
+    stamp();   // 5: S2 of the upper levels
     // ---- 5. crown's workgroup: c_i, e_i -> cbuf;  subtrees: backward sweep above the bottom level, q_root -> qroot, d_i -> dbuf
     if (crown_blk) {
-        real *cb = a.cbuf + (long)inst * igroup_nonleaf(d, dm.t0 + 1) * nxu;
-        x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
-            TState<P> &s = st.s;
-            if (tid >= 64 || !s.active) return;
-            SPK_UNROLL for (int k = 0; k < nx; ++k) cb[tid * nx + k] = s.xb[k];
-            SPK_UNROLL for (int k = 0; k < nu; ++k) cb[nl_grp * nx + tid * nu + k] = s.ub[k];
+        real *cb = a.cbuf + (long)inst * igroup_nonleaf(d, dm.t0 + 1) * nxu;   // layout [c of every crown node | e of every crown node]
+        x.each([&](int tid, RState<P> &) SPK_ILAMBDA {
+            for (int k = tid; k < nl_grp * nx; k += nthr) cb[k] = tl.XQ[k];
+            for (int k = tid; k < nl_grp * nu; k += nthr) cb[nl_grp * nx + k] = tl.ED[k];
         });
     } else {
-        real *q_out = a.qroot + ((long)inst * dm.nsub + g) * dm.nx;
-        x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
-            TState<P> &s = st.s;
-            if (tid >= 64 || !s.active || !s.kids_leaf) return;
-            SPK_UNROLL for (int k = 0; k < nu; ++k) s.dd[k] = s.ub[k];
-            if (s.lvl > 0) { SPK_UNROLL for (int k = 0; k < nx; ++k) exs[tid * nx + k] = s.xb[k]; }
-            else { SPK_UNROLL for (int k = 0; k < nx; ++k) q_out[k] = s.xb[k]; }
-        });
-        x.barrier();
+        // XQ / ED hold c_i / e_i of the upper levels and q_i / d_i of the bottom level: the sweep continues above it
+        x.each([&](int tid, RState<P> &st) SPK_ILAMBDA { team_reg_init(p, dm, M, root_stage, stages, T, tid, st.s, 1); });   // rows of W, V
         for (int l = stages - 3; l >= 0; --l) {
-            const MatPtr SW = M + dm.mSweep + (long)(root_stage + l) * dm.sw_stride;
-            x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
-                if (tid < 64 && st.s.active && st.s.lvl == l) bwd_node(p, dm, SW, tid, exs, (const real *)nullptr, q_out, st.s);
-            });
+            x.each([&](int, RState<P> &st) SPK_ILAMBDA { if (st.s.tn_li >= 0 && st.s.tn_lvl == l) bwd_team_reg(p, stages, tl, st.s); });
             x.barrier();
         }
-        x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
-            TState<P> &s = st.s;
-            if (tid < 64 && s.active) { SPK_UNROLL for (int k = 0; k < nu; ++k) db[s.node * nu + k] = s.dd[k]; }
+        real *q_out = a.qroot + ((long)inst * dm.nsub + g) * dm.nx;
+        x.each([&](int tid, RState<P> &) SPK_ILAMBDA {
+            if (tid < nx) q_out[tid] = tl.XQ[tid];
+            for (int l = 0; l <= stages - 2; ++l) {
+                int lfirst, cnt; long gfirst;
+                level_geo(l, lfirst, cnt, gfirst);
+                for (int k = tid; k < cnt * nu; k += nthr) db[gfirst * nu + k] = tl.ED[lfirst * nu + k];
+            }
         });
     }
+    stamp();   // 6: backward sweep, q_root / d_i stored
     // ---- residual maxima of this workgroup
     x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
         real m3[3];
@@ -199,6 +221,7 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
     });
     x.reduce3();
     x.each([&](int tid, RState<P> &) SPK_ILAMBDA { if (tid < 3) partials[(long)g * kPartialStride + tid] = x.red3(tid); });
+    stamp();   // 7: residual maxima
 }
 
 }  // namespace spock

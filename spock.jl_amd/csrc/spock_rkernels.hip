@@ -23,6 +23,7 @@ struct GpuRExec {
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ real *lds() { return ex; }
     __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
+    __device__ __forceinline__ void clocks(unsigned long long *d) { d[0] = __builtin_readcyclecounter(); d[1] = __builtin_amdgcn_s_memrealtime(); }
     template <class T>
     __device__ __forceinline__ void stash3(int, const T *mx) { m[0] = (double)mx[0]; m[1] = (double)mx[1]; m[2] = (double)mx[2]; }
     // values are |.| (sign bit clear) or NaN: the unsigned order of the bit patterns is the NaN-propagating max order
@@ -46,7 +47,7 @@ struct GpuRExec {
 };
 
 template <class P, bool WX>
-__global__ void __launch_bounds__(64 * (2 + 2 * P::MAXD)) spock_rgroup_kernel(const KArgs a) {
+__global__ void __launch_bounds__(kRgroupThreads) spock_rgroup_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpuRExec<P> x;
     x.ex = reinterpret_cast<real *>(smem);
@@ -60,8 +61,21 @@ static int launch_rvariant(const KArgs &a_in, hipStream_t st) {
     const Dims &dm = a.dm;
     a.ex_doubles = rgroup_lds_doubles(dm.nx, dm.nu, dm.d, a.want_xi != 0);
     const size_t lds = (size_t)a.ex_doubles * 8 + 64;
-    if (lds > 64 * 1024) return (int)hipErrorInvalidConfiguration;
-    const dim3 grid(dm.nsub + 1, a.batch), block(64 * (2 + 2 * dm.d));
+    if (lds > 128 * 1024) return (int)hipErrorInvalidConfiguration;
+    if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (nx = nu = 5 with the L'xi_2 rows): raise it once per kernel and device
+        static bool raised_dev[16][2] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+        bool always = false;
+        bool &raised_flag = dev >= 0 ? raised_dev[dev][a.want_xi ? 1 : 0] : always;
+        if (!raised_flag) {
+            const void *fn = a.want_xi ? (const void *)spock_rgroup_kernel<P, true> : (const void *)spock_rgroup_kernel<P, false>;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised_flag = true;
+        }
+    }
+    const dim3 grid(dm.nsub + 1, a.batch), block(kRgroupThreads);
     if (a.want_xi) hipLaunchKernelGGL((spock_rgroup_kernel<P, true>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((spock_rgroup_kernel<P, false>), grid, block, lds, st, a);
     return (int)hipGetLastError();

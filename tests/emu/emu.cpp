@@ -291,6 +291,7 @@ struct EmuRExec {
     real *lds() { return ex.data(); }
     int nthreads() const { return nthreads_v; }
     void stash3(int tid, const real *mx) { m[tid] = {mx[0], mx[1], mx[2]}; }
+    void clocks(unsigned long long *d) { d[0] = 0; d[1] = 0; }
     void reduce3() {
         for (int k = 0; k < 3; ++k) r3[k] = 0.;
         for (int t = 0; t < nthreads_v; ++t) for (int k = 0; k < 3; ++k) r3[k] = spk_max_nan(r3[k], m[t][k]);
@@ -303,7 +304,7 @@ static int launch_rvariant(const KArgs &a_in) {
     const Dims &dm = a.dm;
     a.ex_doubles = rgroup_lds_doubles(dm.nx, dm.nu, dm.d, a.want_xi != 0);
     const bool rev = env_on("SPOCK_EMU_REVERSE_BLOCKS");
-    const int gx = dm.nsub + 1, thr = 64 * (2 + 2 * dm.d);
+    const int gx = dm.nsub + 1, thr = kRgroupThreads;
     for (int inst = 0; inst < a.batch; ++inst)
         for (int gi = 0; gi < gx; ++gi) {
             const int g = rev ? gx - 1 - gi : gi;

@@ -414,6 +414,7 @@ def test_emulated_fused_iteration_is_order_independent(S, O, emu, env, ok, monke
     crown's workgroup running first must then expose the cross-workgroup read-after-write the recomputation removes."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SPOCK_AMD_RLANE", "0")   # (this test is about SUB_BA; the role-lane kernel that replaces it for few workgroups has its own)
     specs = S.get_server_heat_specs(7, 5, 2, nu=2)
     flat = S.flatten_problem(*specs)
     o = O.Oracle(flat, O.CP)
