@@ -275,7 +275,8 @@ int ilevel_ex_doubles(int mode, const Dims &dm, int want_xi);
 // role-lane subtree kernel (spock_rgroup.hpp), LDS doubles: [sweep vectors XQ 64 nx | ED 64 nu | UL 64 nu | XL 64 d nx][given rows (nx + nu + d nx) 64]
 // [role exchange rows 64][s entries 64]; threads per workgroup: one wave per role, and T = 8 lanes per node for the lane-team sweeps
 constexpr int rgroup_lds_doubles(int nx, int nu, int d, bool wx) {
-    return 64 * nx + 2 * 64 * nu + 64 * d * nx + (nx + nu + d * nx) * 64 + lba_exchange_rows(nx, nu, d, wx) * 64 + 64;
+    return 64 * nx + 2 * 64 * nu + 64 * d * nx + (nx + nu + d * nx) * 64 + lba_exchange_rows(nx, nu, d, wx) * 64 + 64
+           + 7 * (2 * d * nx * nx + d * nu * nx + nu * nx);   // + the sweep blocks [W | V | ABK | K] of up to seven stages (groups of <= 64 nodes)
 }
 constexpr int kRgroupThreads = 512;
 

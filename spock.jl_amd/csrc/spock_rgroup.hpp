@@ -40,7 +40,9 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
     const Dims &dm = a.dm;
     const P p(dm);
     Ctl &ctl = a.ctl[inst];
-    if (ctl.done) return;
+    // (the control block was written by the crown kernel, possibly on another XCD: its load is a cold miss.  The branch on it comes after
+    // the first batch of loads below has been issued, so that all of them share one round trip)
+    const int done_flag = ctl.done;
     const int nx = p.nx(), nu = p.nu(), d = p.d(), ny = p.ny(), nxu = nx + nu;
     const MatPtr M = (MatPtr)(a.mats + (long)inst * a.mats_stride);
     const real *z = a.z_in + (long)inst * a.stride_z, *v = a.v_in + (long)inst * a.stride_v;
@@ -58,6 +60,7 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
     TeamLds tl;
     tl.XQ = x.lds(); tl.ED = tl.XQ + 64 * nx; tl.UL = tl.ED + 64 * nu; tl.XL = tl.UL + 64 * nu;
     real *const G = tl.XL + 64 * d * nx, *const exr = G + (long)(nxu + d * nx) * 64, *const sown = exr + (long)rows * 64;
+    real *const lmat = sown + 64;   // the sweep blocks [W | V | ABK | K] of this group's stages, staged for the backward sweep's rows
     const int T = 8, nthr = x.nthreads();   // register-resident lane-team sweep (bwd_team_reg / fwd_team_reg): T lanes per node, T * nodes <= threads
     auto level_geo = [&](int l, int &lfirst, int &cnt, long &gfirst) SPK_ILAMBDA {
         cnt = 1; lfirst = 0;
@@ -74,6 +77,7 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
         ++stamp_idx;
     };
     stamp();   // 0: entry
+    x.max3_init();   // (LDS accumulators of the residual maxima: zeroed here, ordered by the barriers below)
     x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
         init_geometry(p, dm, tid & 63, root_stage, root_pos, stages, crown_blk, st.s);
         st.mx[0] = st.mx[1] = st.mx[2] = st.mx[3] = 0.;
@@ -95,7 +99,10 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
                 level_geo(l, lfirst, cnt, gfirst);
                 for (int k = tid; k < cnt * nu; k += nthr) tl.ED[lfirst * nu + k] = db[gfirst * nu + k];
             }
+            const MatPtr src = M + dm.mSweep + (long)root_stage * dm.sw_stride;
+            for (int k = tid; k < (stages - 1) * dm.sw_stride; k += nthr) lmat[k] = src[k];
         });
+        if (done_flag) return;
         x.barrier();
         stamp();   // 1: d_i, x_root in LDS
         for (int l = 0; l <= stages - 2; ++l) {
@@ -105,16 +112,15 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
         stamp();   // 2: forward sweep
         // x_i, u_i, x_leaf: coalesced level chunks -> zbar, and transposed into the given rows [x_i | u_i | x_leaf c], one column per node
         x.each([&](int tid, RState<P> &) SPK_ILAMBDA {
+            // (a store to global memory is waited for at the next barrier: only x_i goes to zbar here -- XQ is overwritten by c_i / q_i
+            // later; u_i and x_leaf follow from UL / XL at the end of the kernel, where nothing waits for them)
             for (int l = 0; l <= stages - 2; ++l) {
                 int lfirst, cnt; long gfirst;
                 level_geo(l, lfirst, cnt, gfirst);
                 for (int k = tid; k < cnt * nx; k += nthr) zo[dm.zx + gfirst * nx + k] = tl.XQ[lfirst * nx + k];
-                for (int k = tid; k < cnt * nu; k += nthr) zo[dm.zu + gfirst * nu + k] = tl.UL[lfirst * nu + k];
             }
             int lfirst, cnt; long gfirst;
             level_geo(stages - 2, lfirst, cnt, gfirst);
-            const long gl_first = dm.first[root_stage + stages - 1] + (long)root_pos * cnt * d;
-            for (int k = tid; k < cnt * d * nx; k += nthr) zo[dm.zx + gl_first * nx + k] = tl.XL[k];
             for (int k = tid; k < nl_grp * nx; k += nthr) { const int li = k / nx, e = k - li * nx; G[e * 64 + li] = tl.XQ[k]; }
             for (int k = tid; k < nl_grp * nu; k += nthr) { const int li = k / nu, e = k - li * nu; G[(nx + e) * 64 + li] = tl.UL[k]; }
             for (int k = tid; k < cnt * d * nx; k += nthr) {   // leaf (pos d + c) entry e -> row nxu + c nx + e of its parent's column
@@ -123,10 +129,11 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
             }
         });
     } else {
-        x.each([&](int tid, RState<P> &) SPK_ILAMBDA {   // the crown's nodes are the global nodes 0 .. nl_grp - 1
+        x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {   // the crown's nodes are the global nodes 0 .. nl_grp - 1
             for (int k = tid; k < nl_grp * nx; k += nthr) { const int li = k / nx, e = k - li * nx; G[e * 64 + li] = zo[dm.zx + k]; }
             for (int k = tid; k < nl_grp * nu; k += nthr) { const int li = k / nu, e = k - li * nu; G[(nx + e) * 64 + li] = zo[dm.zu + k]; }
         });
+        if (done_flag) return;
     }
     x.barrier();
     stamp();   // 3: zbar stored, x / u handed to the role lanes
@@ -170,7 +177,14 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
             x.sync();
         }
     });
+    // residual maxima of this workgroup: complete once the roles' finishing parts have run; folded into LDS in front of the barrier
+    x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
+        real m3[3];
+        for (int k = 0; k < 3; ++k) m3[k] = (st.mx[3] != st.mx[3]) ? st.mx[3] : st.mx[k];
+        x.max3_add(tid, m3);
+    });
     x.barrier();
+    x.each([&](int tid, RState<P> &) SPK_ILAMBDA { if (tid < 3) partials[(long)g * kPartialStride + tid] = x.max3_get(tid); });
     stamp();   // 4: role step
     // ---- 4. S2 of the levels above the bottom one (implicit_l.jl:708-726)
     x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
@@ -197,7 +211,19 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
         });
     } else {
         // XQ / ED hold c_i / e_i of the upper levels and q_i / d_i of the bottom level: the sweep continues above it
-        x.each([&](int tid, RState<P> &st) SPK_ILAMBDA { team_reg_init(p, dm, M, root_stage, stages, T, tid, st.s, 1); });   // rows of W, V
+        x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {   // this thread's rows of W, V (team_reg_init's part 1), from the staged blocks
+            TState<P> &s = st.s;
+            if (s.tn_li < 0) return;
+            const real *SW = lmat + (long)s.tn_lvl * dm.sw_stride;
+            const int r = s.tn_r;
+            SPK_UNROLL for (int c = 0; c < d; ++c) {
+                const real *W = SW + dm.sw_oW + c * nx * nx, *V = SW + dm.sw_oV + c * nu * nx;
+                SPK_UNROLL for (int k = 0; k < nx; ++k) {
+                    s.tW[c][k] = (r < nx) ? W[r + k * nx] : (real)0.;
+                    s.tV[c][k] = (r < nu) ? V[r + k * nu] : (real)0.;
+                }
+            }
+        });
         for (int l = stages - 3; l >= 0; --l) {
             x.each([&](int, RState<P> &st) SPK_ILAMBDA { if (st.s.tn_li >= 0 && st.s.tn_lvl == l) bwd_team_reg(p, stages, tl, st.s); });
             x.barrier();
@@ -208,20 +234,16 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
             for (int l = 0; l <= stages - 2; ++l) {
                 int lfirst, cnt; long gfirst;
                 level_geo(l, lfirst, cnt, gfirst);
-                for (int k = tid; k < cnt * nu; k += nthr) db[gfirst * nu + k] = tl.ED[lfirst * nu + k];
+                for (int k = tid; k < cnt * nu; k += nthr) { db[gfirst * nu + k] = tl.ED[lfirst * nu + k]; zo[dm.zu + gfirst * nu + k] = tl.UL[lfirst * nu + k]; }
             }
+            int lfirst, cnt; long gfirst;
+            level_geo(stages - 2, lfirst, cnt, gfirst);
+            const long gl_first = dm.first[root_stage + stages - 1] + (long)root_pos * cnt * d;
+            for (int k = tid; k < cnt * d * nx; k += nthr) zo[dm.zx + gl_first * nx + k] = tl.XL[k];
         });
     }
     stamp();   // 6: backward sweep, q_root / d_i stored
-    // ---- residual maxima of this workgroup
-    x.each([&](int tid, RState<P> &st) SPK_ILAMBDA {
-        real m3[3];
-        for (int k = 0; k < 3; ++k) m3[k] = (st.mx[3] != st.mx[3]) ? st.mx[3] : st.mx[k];
-        x.stash3(tid, m3);
-    });
-    x.reduce3();
-    x.each([&](int tid, RState<P> &) SPK_ILAMBDA { if (tid < 3) partials[(long)g * kPartialStride + tid] = x.red3(tid); });
-    stamp();   // 7: residual maxima
+    stamp();   // 7: end
 }
 
 }  // namespace spock

@@ -44,6 +44,22 @@ struct GpuRExec {
         __syncthreads();
     }
     __device__ __forceinline__ real red3(int k) const { return __longlong_as_double((long long)red[k]); }
+    // the same maximum without barriers of its own: max3_init() ... barrier ... max3_add() ... barrier ... max3_get()
+    __device__ __forceinline__ void max3_init() { if (threadIdx.x < 3) red[threadIdx.x] = 0ull; }
+    template <class T>
+    __device__ __forceinline__ void max3_add(int, const T *mx) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            unsigned long long b = (unsigned long long)__double_as_longlong((double)mx[k]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(b, off, 64);
+                b = o > b ? o : b;
+            }
+            if ((threadIdx.x & 63) == 0 && b) atomicMax(&red[k], b);
+        }
+    }
+    __device__ __forceinline__ real max3_get(int k) const { return __longlong_as_double((long long)red[k]); }
 };
 
 template <class P, bool WX>

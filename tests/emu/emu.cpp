@@ -297,6 +297,9 @@ struct EmuRExec {
         for (int t = 0; t < nthreads_v; ++t) for (int k = 0; k < 3; ++k) r3[k] = spk_max_nan(r3[k], m[t][k]);
     }
     real red3(int k) const { return r3[k]; }
+    void max3_init() { for (int k = 0; k < 3; ++k) r3[k] = 0.; }
+    void max3_add(int, const real *mx) { for (int k = 0; k < 3; ++k) r3[k] = spk_max_nan(r3[k], mx[k]); }
+    real max3_get(int k) const { return r3[k]; }
 };
 template <class P>
 static int launch_rvariant(const KArgs &a_in) {

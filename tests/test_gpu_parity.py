@@ -651,6 +651,74 @@ def test_bench_regime_matches_oracle(S, O):
     m.close()
 
 
+def test_two_bottom_stages_in_one_launch(S, O, monkeypatch):
+    """LBA2 (spock_ilevel.hpp: LB of stage N-3, LBA of stage N-2 and LA of stage N-3 as one launch, hand-offs in LDS) on the GPU:
+    bitwise the iterates of the three-launch sequence (SPOCK_AMD_ILV_FUSE2=0) -- the same role functions, the same arithmetic per
+    entry -- over several tiles with a partial one, SILENT and LOG mode (other kernel variant), d = 2 at BASELINE config 2's full
+    tree and d = 3; three instances against the oracle."""
+    cases = [(S.get_server_heat_specs(13, 5, 2, nu=2), {}, 200, 24), (S.get_server_heat_specs(9, 5, 2), {"split_stage": 2}, 70, 40),
+             (S.get_random_linear_specs(6, 3, 2, d=3), {"split_stage": 2}, 70, 40)]
+    for specs, kw, B, iters in cases:
+        flat = S.flatten_problem(*specs)
+        x0 = 0.1 * (1 + 0.003 * np.arange(B))[:, None] * np.cos(np.arange(flat.nx))[None, :]
+        out = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("SPOCK_AMD_ILV_FUSE2", fuse)
+            m = S.build_model(*specs, batch=B, layout="interleaved", max_iter=iters, **kw)
+            names = [n for n, _, _ in m.profile_sequence(1)]
+            assert ("lba2" in names) == (fuse == "1")
+            res = []
+            for verbose in (S.SILENT, S.LOG):
+                m.reset()
+                rs = S.solve_model(m, x0, tol=0.0, verbose=verbose)
+                res.append((m.solver_state.z.copy(), m.solver_state.v.copy(), m.history(B - 1)["xi1"].copy()))
+            if fuse == "1":
+                for b in (0, B // 2, B - 1):
+                    o = O.Oracle(flat, O.CP); o.solve(x0[b], tol=0.0, max_iter=iters, verbose=O.LOG)
+                    assert relerr(m.solver_state.z[b], o.z) <= 1e-9 and relerr(m.solver_state.v[b], o.v) <= 1e-9
+            out[fuse] = res
+            m.close()
+        for (z1, v1, h1), (z0, v0, h0) in zip(out["1"], out["0"]):
+            assert np.array_equal(z1, z0) and np.array_equal(v1, v0) and np.array_equal(h1, h0)
+
+
+def test_role_lane_subtree_kernel(S, O, monkeypatch):
+    """MODE_SUB_BA_R (spock_rgroup.hpp) on the GPU: the single-instance regime's fused iteration with the node-local phases split over
+    role lanes -- BASELINE config 2's tree (4096 leaves, nu = 2 and nu = 5: the larger shape runs the fused sequence only with this
+    kernel), one and three instances, SILENT and LOG mode, a small d = 3 tree; against the oracle (whole solves: identical iteration
+    counts, iterates <= 1e-8) and, to rounding, against the kernels it replaces (SPOCK_AMD_RLANE=0); bitwise repeatable."""
+    cases = [(S.get_server_heat_specs(13, 5, 2, nu=2), {}, 1, 150, 0.0), (S.get_server_heat_specs(13, 5, 2), {}, 3, 400, 2e-3),
+             (S.get_random_linear_specs(6, 3, 2, d=3), {"split_stage": 3}, 2, 150, 1e-5)]
+    for specs, kw, B, iters, tol in cases:
+        flat = S.flatten_problem(*specs)
+        x0 = 0.1 * (1 + 0.05 * np.arange(B))[:, None] * np.ones((B, flat.nx))
+        out = {}
+        for rl in ("1", "0"):
+            monkeypatch.setenv("SPOCK_AMD_RLANE", rl)
+            m = S.build_model(*specs, batch=B, max_iter=iters, **kw)
+            names = [n for n, _, _ in m.profile_sequence(1)]
+            assert ("sub_ba_r" in names) == (rl == "1"), names
+            res = []
+            for verbose, ov in ((S.SILENT, O.SILENT), (S.LOG, O.LOG)):
+                m.reset()
+                rs = S.solve_model(m, x0 if B > 1 else x0[0], tol=tol, verbose=verbose)
+                rs = rs if isinstance(rs, list) else [rs]
+                Z = m.solver_state.z.reshape(B, -1).copy(); V = m.solver_state.v.reshape(B, -1).copy()
+                res.append((Z, V, [r["iterations"] for r in rs]))
+                if rl == "1":
+                    for b in (0, B - 1):
+                        o = O.Oracle(flat, O.CP); ro = o.solve(x0[b], tol=tol, max_iter=iters, verbose=ov)
+                        assert (rs[b]["iterations"], rs[b]["status"]) == (ro["iterations"], ro["status"])
+                        assert relerr(Z[b], o.z) <= 1e-8 and relerr(V[b], o.v) <= 1e-8
+                    m.reset()
+                    S.solve_model(m, x0 if B > 1 else x0[0], tol=tol, verbose=verbose)
+                    assert np.array_equal(m.solver_state.z.reshape(B, -1), Z)     # bitwise repeatable
+            out[rl] = res
+            m.close()
+        for (z1, v1, it1), (z0, v0, it0) in zip(out["1"], out["0"]):
+            assert it1 == it0 and relerr(z1.ravel(), z0.ravel(), blocks=False) <= 1e-10 and relerr(v1.ravel(), v0.ravel(), blocks=False) <= 1e-10
+
+
 def test_mpc_steps_chained_on_the_device(S, O, monkeypatch):
     """The closed loop of examples/server_heat/mpc_simulation.jl:47-54,164-177 with its steps chained on the device (SP_CTL_M): per-step
     iteration counts, statuses and trajectories identical to the host loop of solve calls (SPOCK_AMD_MPC_HOST=1) -- the instances
