@@ -719,6 +719,30 @@ def test_role_lane_subtree_kernel(S, O, monkeypatch):
             assert it1 == it0 and relerr(z1.ravel(), z0.ravel(), blocks=False) <= 1e-10 and relerr(v1.ravel(), v0.ravel(), blocks=False) <= 1e-10
 
 
+def test_role_lane_subtree_kernel_fp32_library(S, O):
+    """MODE_SUB_BA_R in libspock_amd_f32.so (rows of floats in LDS, the same role functions): one instance of the nu = 5 and nu = 2 trees
+    against the fp64 oracle at single-precision tolerances -- 60 iterations, and a solve to tol 1e-3 (nu = 5)."""
+    for nu in (5, 2):
+        specs = S.get_server_heat_specs(9, 5, 2, nu=nu)
+        flat = S.flatten_problem(*specs)
+        x0 = np.full(5, 0.1)
+        m = S.build_model(*specs, max_iter=60, dtype="f32")
+        assert m.dtype == "f32" and "sub_ba_r" in [n for n, _, _ in m.profile_sequence(1)]
+        m.reset()
+        S.solve_model(m, x0, tol=0.0)
+        o = O.Oracle(flat, O.CP); o.solve(x0, tol=0.0, max_iter=60)
+        assert relerr(m.solver_state.z, o.z, blocks=False) <= 2e-5 and relerr(m.solver_state.v, o.v, blocks=False) <= 2e-5
+        m.close()
+    specs = S.get_server_heat_specs(9, 5, 2)
+    flat = S.flatten_problem(*specs)
+    m = S.build_model(*specs, max_iter=1500, dtype="f32")
+    r = S.solve_model(m, np.full(5, 0.1), tol=1e-3)
+    o = O.Oracle(flat, O.CP); ro = o.solve(np.full(5, 0.1), tol=1e-3, max_iter=1500)
+    assert r["status"] == ro["status"] == 0 and abs(r["iterations"] - ro["iterations"]) <= max(2, ro["iterations"] // 50)
+    assert relerr(m.solver_state.z, o.z, blocks=False) <= 2e-3
+    m.close()
+
+
 def test_mpc_steps_chained_on_the_device(S, O, monkeypatch):
     """The closed loop of examples/server_heat/mpc_simulation.jl:47-54,164-177 with its steps chained on the device (SP_CTL_M): per-step
     iteration counts, statuses and trajectories identical to the host loop of solve calls (SPOCK_AMD_MPC_HOST=1) -- the instances
