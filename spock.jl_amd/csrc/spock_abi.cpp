@@ -467,6 +467,7 @@ int sp_init_state(spock_handle_s *h) {
     SpCtl c;
     std::memset(&c, 0, sizeof(c));
     c.R[0] = c.R[4] = c.R[8] = 1.;
+    c.crho[0] = c.crho[1] = c.crho[2] = 1.;
     c.r_safe = INFINITY;
     h->h_sp.assign(B, c);
     if (!e) e = rt::h2d(h->s_ctl, h->h_sp.data(), B * sizeof(SpCtl), h->stream);

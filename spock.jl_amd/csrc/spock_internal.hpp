@@ -153,6 +153,8 @@ struct SpCtl {          // per instance, device memory; survives between solves 
     double r_safe, rnorm, rtilde, rho_dot, coef;
     double r2, r3, rho, g[3];
     double xi_fb[2];    // residuals of the plain CP step z <- T(z) (the fall-back), kept from the first T evaluation
+    double crho[3];     // norm of each PHYSICAL column of Q: the columns are stored unnormalised and divided where they are read
+                        // (spock_sp.hpp: FLAT1 / FLAT2); 1 initially
 };
 
 constexpr int kSpSums = 10;   // partial sums per workgroup of the flat / LOP kernels

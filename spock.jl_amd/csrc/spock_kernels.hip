@@ -176,9 +176,12 @@ __global__ void __launch_bounds__(kFlatThreads) spock_sp_flat_kernel(const SpArg
     if (done == 1 || (done && a.op != SP_FLAT5)) return;   // done == 2: the state update of the final iteration still runs
     __shared__ double red[9 * 16];
     const SpCtl c = a.sp[inst];
+    // (the two column norms by their own loads from the control block: a dynamic index into the register copy `c` would send it to scratch)
+    const int hd = a.sp[inst].head;
+    const double rho2 = a.sp[inst].crho[(hd + 1) % 3], rho3 = a.sp[inst].crho[(hd + 2) % 3];
     double sums[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
     const long stride = (long)gridDim.x * kFlatThreads;
-    for (long e = (long)blockIdx.x * kFlatThreads + threadIdx.x; e < a.nr; e += stride) sp_flat_elem(a, c, inst, e, sums);
+    for (long e = (long)blockIdx.x * kFlatThreads + threadIdx.x; e < a.nr; e += stride) sp_flat_elem(a, c, inst, e, sums, rho2, rho3);
     if (a.op == SP_FLAT1 || a.op == SP_FLAT2) {
         block_reduce<9, false>(sums, red);
         if (threadIdx.x == 0) {

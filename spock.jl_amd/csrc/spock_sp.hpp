@@ -9,7 +9,7 @@
 //   CTL_A   rnorm, Gram-Schmidt coefficients r2, r3, shift of R; keeps T(Z)'s CP residuals   (anderson.jl:46-50,76-88)
 //   FLAT2   Q1 = dr - r2 Q2 - r3 Q3, its norm, Q'r                           (anderson.jl:88-110)
 //   CTL_B   R11, gamma = R^-1 Q'r                                            (anderson.jl:94-113)
-//   FLAT3   Q1 /= rho, d = -r - MP gamma, candidate W = Z + d                (anderson.jl:116-122, sp.jl:118-131)
+//   FLAT3   d = -r - MP gamma, candidate W = Z + d (Q1 /= rho: where it is read)  (anderson.jl:116-122, sp.jl:118-131)
 //   T(W) -> WB     phase B also accumulates <rt, P rt>, <rt, P d> (SPM = 2) and forms the termination residuals of d
 //   CTL_CD  K1 / K2 / fall-back decision, r_safe, backtrack count (sp.jl:411-446); termination test, history,
 //           counters (sp.jl:295-344, :464) with the residuals of dp taken by linearity from the two evaluations
@@ -33,7 +33,10 @@ SPK_DEV int sp_col(const SpCtl &c, int logical /*0 = newest*/) { return (c.head 
 
 // ---------------------------------------------------------------------------------------------------
 // flat element-wise steps; `e` is the element index inside the instance's nr-vector, sums[] accumulates
-SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, double *sums) {
+// rho2, rho3: norms of the Q columns at logical positions 1 and 2 (SpCtl::crho, read by the caller from the control block itself: the
+// columns are stored unnormalised and divided where they are read -- bitwise the value FLAT3 used to store -- so that FLAT3 neither
+// reads nor rewrites the newest one)
+SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, double *sums, double rho2, double rho3) {
     const long o = (long)inst * a.nr + e;
     const long m3 = (long)inst * 3 * a.nr;
     real *q1 = a.Q + m3 + (long)sp_col(c, 0) * a.nr, *q2 = a.Q + m3 + (long)sp_col(c, 1) * a.nr,
@@ -50,7 +53,7 @@ SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, dou
             p1[e] = a.DP[o] - dr;                 // MP[:,1] = delta_p - delta_r   (anderson.jl:25-32)
             q1[e] = dr;                           // Q[:,1]  = MR[:,1] = delta_r   (anderson.jl:63-65)
             // (z_old <- z of update_sy! needs no copy either: see FLAT5)
-            const real b = q2[e], cc = q3[e];
+            const real b = (real)(q2[e] / rho2), cc = (real)(q3[e] / rho3);
             sums[0] += dr * dr; sums[1] += b * dr; sums[2] += cc * dr; sums[3] += b * b; sums[4] += cc * cc; sums[5] += b * cc;
             sums[6] += dr * r; sums[7] += b * r; sums[8] += cc * r;      // MR'r: right-hand side of the corrected variant's normal equations
         } break;
@@ -58,13 +61,13 @@ SPK_DEV void sp_flat_elem(const SpArgs &a, const SpCtl &c, int inst, long e, dou
             a.W[o] = a.Z[o] + (real)a.tau * a.D[o];
             break;
         case SP_FLAT2: {
-            const real v = q1[e] - c.r2 * q2[e] - c.r3 * q3[e];   // anderson.jl:88
-            q1[e] = v;
+            const real b = (real)(q2[e] / rho2), cc = (real)(q3[e] / rho3);
+            const real v = q1[e] - c.r2 * b - c.r3 * cc;   // anderson.jl:88
+            q1[e] = v;                                         // stays unnormalised: its norm goes to crho[head] (CTL_B, anderson.jl:94-98)
             const real r = a.R[o];
-            sums[0] += v * v; sums[1] += v * r; sums[2] += q2[e] * r; sums[3] += q3[e] * r;
+            sums[0] += v * v; sums[1] += v * r; sums[2] += b * r; sums[3] += cc * r;
         } break;
         case SP_FLAT3: {
-            q1[e] = q1[e] / c.rho;                                   // anderson.jl:94-98
             const real w = (p1[e] * c.g[0] + p2[e] * c.g[1]) + p3[e] * c.g[2];   // MP gamma (anderson.jl:116)
             const real d = -a.R[o] - w;                            // anderson.jl:117-122
             a.D[o] = d;
@@ -248,10 +251,12 @@ SPK_DEV void sp_ctl_a_ls(SpCtl &c, const double *f, double pr, double xi1, doubl
         g[j] = t / L[j + 3 * j];
     }
     c.g[0] = g[0]; c.g[1] = g[1]; c.g[2] = g[2];
-    c.rho = 1.; c.r2 = 0.; c.r3 = 0.;     // FLAT3's normalisation of the newest column becomes the identity
+    c.rho = 1.; c.r2 = 0.; c.r3 = 0.;     // the normalisation of the newest column becomes the identity
+    c.crho[sp_col(c, 0)] = 1.;
 }
 SPK_DEV void sp_ctl_b(SpCtl &c, const double *s4) {
     c.rho = sqrt(s4[0]);                                             // anderson.jl:70-75 / :93-99
+    c.crho[sp_col(c, 0)] = c.rho;                                    // Q[:, 1] /= rho happens where the column is read
     c.R[0] = c.rho;
     double g[3] = {s4[1] / c.rho, s4[2], s4[3]};                     // gamma = Q' r with Q1 normalised (anderson.jl:110)
     const double *R = c.R;

@@ -413,9 +413,10 @@ int launch_sp(const SpArgs &a, void *) {
             const int done = a.ctl[inst].done;
             if (done == 1 || (done && a.op != SP_FLAT5)) continue;   // done == 2: the state update of the final iteration still runs
             const SpCtl c = a.sp[inst];
+            const double rho2 = c.crho[(c.head + 1) % 3], rho3 = c.crho[(c.head + 2) % 3];
             for (int blk = 0; blk < a.n_partF; ++blk) {
                 real sums[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
-                for (long e = blk; e < a.nr; e += a.n_partF) sp_flat_elem(a, c, inst, e, sums);
+                for (long e = blk; e < a.nr; e += a.n_partF) sp_flat_elem(a, c, inst, e, sums, rho2, rho3);
                 real *dst = a.partF + ((long)inst * a.n_partF + blk) * kSpSums;
                 if (a.op == SP_FLAT1 || a.op == SP_FLAT2) for (int k = 0; k < 9; ++k) dst[k] = sums[k];
             }
