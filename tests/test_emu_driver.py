@@ -803,6 +803,23 @@ def test_emulated_role_lane_subtree_kernel(S, O, emu, monkeypatch, env):
             assert it1 == it0 and relerr(z1, z0) <= 1e-11 and relerr(v1, v0) <= 1e-11
 
 
+def test_role_lane_kernel_is_chosen_by_the_workgroups_in_flight(S, emu, monkeypatch):
+    """rlane_applies (spock_host.cpp): MODE_SUB_BA_R replaces SUB_BA while batch x (subtrees + 1) <= 400 workgroups are in flight (the
+    measured crossover), for compile-time shapes with shared costs and groups of at most 64 nodes; SPOCK_AMD_RLANE=1 lifts the batch
+    rule only, =0 switches the kernel off; SP never uses it; per-instance dynamics keep SUB_BA (one matrix pool per instance)."""
+    monkeypatch.delenv("SPOCK_AMD_RLANE", raising=False)
+    specs = S.get_server_heat_specs(7, 5, 2, nu=2)
+    seq = lambda **kw: [n for n, _, _ in S.build_model(*specs, lib_path=emu, split_stage=3, layout="instance", **kw).profile_sequence(1)]
+    assert seq(batch=44) == ["crown", "sub_ba_r"] and seq(batch=45) == ["crown", "sub_ba"]          # 9 workgroups per instance
+    assert seq(batch=2, per_instance_dynamics=True) == ["crown", "sub_ba"]
+    monkeypatch.setenv("SPOCK_AMD_RLANE", "1")
+    assert seq(batch=45) == ["crown", "sub_ba_r"]
+    big = S.get_server_heat_specs(9, 5, 2, nu=2)      # split 1: subtrees of 255 nodes -- no lane per node
+    assert [n for n, _, _ in S.build_model(*big, lib_path=emu, split_stage=1).profile_sequence(1)] == ["crown", "sub_ba"]
+    monkeypatch.setenv("SPOCK_AMD_RLANE", "0")
+    assert seq(batch=1) == ["crown", "sub_ba"]
+
+
 @pytest.mark.parametrize("env", [{}, {"SPOCK_EMU_REVERSE": "1"}, {"SPOCK_EMU_REVERSE_BLOCKS": "1"}, {"SPOCK_AMD_ILV_CHUNK": "3"}])
 def test_emulated_two_bottom_stages_in_one_launch(S, O, emu, monkeypatch, env):
     """LBA2 (spock_ilevel.hpp): LB of stage N-3, LBA of stage N-2 and LA of stage N-3 as one launch -- x and q of the children,
