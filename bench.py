@@ -444,6 +444,7 @@ def main(argv=None):
             torch.cuda.synchronize(); t = time.perf_counter(); r = S.solve_model(m1, x0[:1], tol=0.0); dt = time.perf_counter() - t
             single["iterations_per_s"] = round(r["iterations"] / dt, 1)
             single["us_per_iteration_device"] = round(r["solve_ms"] / r["iterations"] * 1e3, 2)
+            single["kernel_sequence"] = [n for n, _, _ in m1.profile_sequence(2)]   # (sub_ba_r: the role-lane subtree kernel, spock_rgroup.hpp)
             m1.close()
             specs5 = S.get_server_heat_specs(N_REF, NX, D)           # reference-faithful nu = nx = 5: converges
             flat5 = S.flatten_problem(*specs5)
@@ -452,6 +453,7 @@ def main(argv=None):
             r5 = S.solve_model(m5, np.full(NX, 0.1), tol=1e-3)
             single["ms_to_tol_1e-3_nu5"] = round(r5["solve_ms"], 3)
             single["iterations_to_tol_nu5"] = r5["iterations"]
+            single["kernel_sequence_nu5"] = [n for n, _, _ in m5.profile_sequence(2)]
             m5.close()
             # the Spock algorithm proper (SuperMann-accelerated CP, SolverOptions(SP, nothing)) on the same convergent tree
             ms = S.build_model(*specs5, S.SolverOptions(S.SP, None), batch=1, device=dev_index)
