@@ -228,7 +228,10 @@ bool rlane_applies(const Dims &dm, int batch, bool fused) {
     if (dm.nx > 8 || dm.nu > 8 || 64 * (2 + 2 * dm.d) > kRgroupThreads) return false;
     if ((long)rgroup_lds_doubles(dm.nx, dm.nu, dm.d, true) * 8 + 64 > 128 * 1024) return false;
     if (e && e[0] == '1') return true;
-    return (long)batch * (dm.nsub + 1) <= 400;   // (measured, 4096 leaves, 65 workgroups per instance: 1.3-1.6 x faster up to 6 instances, slower from 8 on)
+    // measured (profiles/r03/rlane_batch_crossover.log; 4096 leaves = 65 workgroups per instance, 512 leaves = 17): against SUB_BA
+    // (nx + nu <= 8) 1.3-1.6 x faster up to ~400 workgroups in flight, slower from ~520 on; against the three-launch sequence of the
+    // larger shapes still 1.07-1.16 x faster at 520-750
+    return (long)batch * (dm.nsub + 1) <= (dm.nx + dm.nu <= 8 ? 400 : 800);
 }
 
 bool team_local_applies(const Dims &dm) {

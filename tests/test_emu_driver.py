@@ -804,13 +804,16 @@ def test_emulated_role_lane_subtree_kernel(S, O, emu, monkeypatch, env):
 
 
 def test_role_lane_kernel_is_chosen_by_the_workgroups_in_flight(S, emu, monkeypatch):
-    """rlane_applies (spock_host.cpp): MODE_SUB_BA_R replaces SUB_BA while batch x (subtrees + 1) <= 400 workgroups are in flight (the
-    measured crossover), for compile-time shapes with shared costs and groups of at most 64 nodes; SPOCK_AMD_RLANE=1 lifts the batch
+    """rlane_applies (spock_host.cpp): MODE_SUB_BA_R replaces SUB_BA while batch x (subtrees + 1) <= 400 workgroups are in flight (800 for the
+    shapes whose alternative is the three-launch sequence: the measured crossovers), for compile-time shapes with shared costs and groups of at most 64 nodes; SPOCK_AMD_RLANE=1 lifts the batch
     rule only, =0 switches the kernel off; SP never uses it; per-instance dynamics keep SUB_BA (one matrix pool per instance)."""
     monkeypatch.delenv("SPOCK_AMD_RLANE", raising=False)
     specs = S.get_server_heat_specs(7, 5, 2, nu=2)
     seq = lambda **kw: [n for n, _, _ in S.build_model(*specs, lib_path=emu, split_stage=3, layout="instance", **kw).profile_sequence(1)]
     assert seq(batch=44) == ["crown", "sub_ba_r"] and seq(batch=45) == ["crown", "sub_ba"]          # 9 workgroups per instance
+    specs5 = S.get_server_heat_specs(7, 5, 2)         # nx + nu > 8: the alternative is the three-launch sequence -- up to 800 workgroups
+    seq5 = lambda **kw: [n for n, _, _ in S.build_model(*specs5, lib_path=emu, split_stage=3, layout="instance", **kw).profile_sequence(1)]
+    assert seq5(batch=88) == ["crown", "sub_ba_r"] and seq5(batch=89)[0] == "sub_a"
     assert seq(batch=2, per_instance_dynamics=True) == ["crown", "sub_ba"]
     monkeypatch.setenv("SPOCK_AMD_RLANE", "1")
     assert seq(batch=45) == ["crown", "sub_ba_r"]
