@@ -768,12 +768,15 @@ def test_emulated_role_lane_subtree_kernel(S, O, emu, monkeypatch, env):
     """MODE_SUB_BA_R (spock_rgroup.hpp): the fused iteration's subtree kernel with the node-local phases split over role lanes (wave =
     role, lane = node) -- chosen for compile-time shapes with few workgroups in flight.  Against the oracle (SILENT and LOG mode: the
     kernel variant with the combined residual), in both thread / workgroup orders, several splits (subtrees of one to five levels, a
-    one-node crown), d = 2 and d = 3, two instances; equal to rounding to MODE_SUB_BA (SPOCK_AMD_RLANE=0), whose sums over the children
+    one-node crown), d = 2 and d = 3, a second-order risk cone, two instances; equal to rounding to MODE_SUB_BA (SPOCK_AMD_RLANE=0), whose sums over the children
     run in another order."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cases = [(S.get_server_heat_specs(7, 5, 2, nu=2), s) for s in (1, 3, 5)] + [(S.get_server_heat_specs(6, 5, 2), 2), (S.get_random_linear_specs(5, 3, 2, d=3), 2),
                                                                                 (S.get_random_linear_specs(7, 2, 1), 3)]
+    tree, cost, dyn, _, con = S.get_server_heat_specs(6, 5, 2, nu=2)     # a second-order sub-cone in the risk cone (role R's projection)
+    E = np.vstack([0.95 * np.eye(2), -np.eye(2), np.ones((1, 2))]); F = np.zeros((5, 2)); b = np.array([0.3, 0.7, 0, 0, 1.0])
+    cases.append(((tree, cost, dyn, S.get_uniform_rms_v2(E, F, b, S.ConvexCone([(S.CONE_SOC, 3), (S.CONE_NONNEG, 1), (S.CONE_REALS, 1)]), 2, 6), con), 2))
     for specs, split in cases:
         flat = S.flatten_problem(*specs)
         x0 = np.stack([0.1 * np.cos(np.arange(flat.nx)), 0.13 * np.ones(flat.nx)])
