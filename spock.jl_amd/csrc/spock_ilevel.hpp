@@ -75,6 +75,9 @@ SPK_DEV void lv_role_x(const P &p, const Dims &dm, MatPtr SW, MatPtr Bm, ZI z, V
     if (gu) {
         SPK_UNROLL for (int k = 0; k < nx; ++k) lr.xi[k] = xs[k];
         SPK_UNROLL for (int k = 0; k < nu; ++k) { lr.ui[k] = gu[k]; di[k] = 0.; }
+        // (x_i goes to zbar from here: a store in front of the hand-off's barrier would be waited for there, ~1 us; the barrier that
+        // closes the role step waits for this role's loads anyway)
+        SPK_UNROLL for (int k = 0; k < nx; ++k) zo[dm.zx + i * nx + k] = lr.xi[k];
     } else lv_load_xd(p, dm, zo, db, i, lr.xi, di, xs);
     real zx_[P::MAXNX], zu_[P::MAXNU], v7[P::MAXNX + P::MAXNU];
     SPK_UNROLL for (int k = 0; k < nx; ++k) zx_[k] = z[dm.zx + i * nx + k];

@@ -112,13 +112,8 @@ SPK_DEV void rgroup_body(X &x, const KArgs &a, int inst, int g) {
         stamp();   // 2: forward sweep
         // x_i, u_i, x_leaf: coalesced level chunks -> zbar, and transposed into the given rows [x_i | u_i | x_leaf c], one column per node
         x.each([&](int tid, RState<P> &) SPK_ILAMBDA {
-            // (a store to global memory is waited for at the next barrier: only x_i goes to zbar here -- XQ is overwritten by c_i / q_i
-            // later; u_i and x_leaf follow from UL / XL at the end of the kernel, where nothing waits for them)
-            for (int l = 0; l <= stages - 2; ++l) {
-                int lfirst, cnt; long gfirst;
-                level_geo(l, lfirst, cnt, gfirst);
-                for (int k = tid; k < cnt * nx; k += nthr) zo[dm.zx + gfirst * nx + k] = tl.XQ[lfirst * nx + k];
-            }
+            // (a store to global memory is waited for at the next barrier: x_i goes to zbar from role X's lanes inside the role step --
+            // XQ is overwritten by c_i / q_i later --, u_i and x_leaf from UL / XL at the end of the kernel, where nothing waits for them)
             int lfirst, cnt; long gfirst;
             level_geo(stages - 2, lfirst, cnt, gfirst);
             for (int k = tid; k < nl_grp * nx; k += nthr) { const int li = k / nx, e = k - li * nx; G[e * 64 + li] = tl.XQ[k]; }
